@@ -1,0 +1,183 @@
+/*
+ * include/spp_hip.h -- C ABI of libspp_hip.so, the MI355X (gfx950) block-sparse Lambda solver
+ * that drops in behind SLAM++'s duck-typed CLinearSolver_* concept.
+ *
+ * The reference has NO C ABI for this path: a linear solver is a C++ template concept
+ * (reference: include/slam/LinearSolverTags.h:38,54,64-135; the native model is
+ * include/slam/LinearSolver_UberBlock.h:44-427, the Schur wrapper include/slam/LinearSolver_Schur.h:1423-2392).
+ * include/spp_adapter.h implements that concept on top of these entry points; INTEGRATION.md
+ * shows how the reference is recompiled against it without source edits.
+ *
+ * Conventions
+ *   - every function returns SPP_OK (0), SPP_NOT_POSDEF (1: the adapter maps it to `return false`,
+ *     reference: BlockMatrix.cpp:9765-9771 / NonlinearSolver_Lambda.h:628-664), or a negative
+ *     SPP_E_* code (the adapter throws std::runtime_error / std::bad_alloc, reference:
+ *     LinearSolver_Schur_GPU.cpp:734-797); spp_last_error() returns the message.
+ *   - plain pointers and sizes only; int64 block indices / offsets, int32 block dims, fp64 values.
+ *   - pointers named h_* are host memory, d_* are device (HBM) memory of the ctx's device.
+ *   - one ctx = one device + one stream, used from one thread (reference threading contract:
+ *     LinearSolver_Schur.h:1187 binds one context per solver instance).
+ *   - there is NO CPU fallback: every compute entry point fails with SPP_E_NO_DEVICE if HIP
+ *     cannot run on the selected device.
+ *
+ * Matrix layout (the flattening of CUberBlockMatrix, reference BlockMatrixBase.h:380-503):
+ *   upper-triangular block-CSC; nb block columns; dim[nb] widths; col_ptr[nb+1]; row_idx[nnzb]
+ *   ascending per column with the diagonal block last; blk_off[nnzb] = offset in doubles of block
+ *   p inside `vals`; a block is dim[row] x dim[col], column-major (the element order
+ *   t_Block_AtColumn(...).data() yields, BlockMatrix.h:343-485).
+ */
+#ifndef SPP_HIP_H
+#define SPP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPP_OK            0
+#define SPP_NOT_POSDEF    1
+#define SPP_E_BADARG     -1
+#define SPP_E_NOMEM      -2
+#define SPP_E_HIP        -3
+#define SPP_E_NO_DEVICE  -4
+#define SPP_E_STATE      -5   /* call order violated (e.g. solve before analyze) */
+#define SPP_E_UNSUPPORTED -6
+
+/* spp_analyze modes */
+#define SPP_MODE_AUTO     0   /* Schur if two block widths with a block-diagonal landmark part, else sparse */
+#define SPP_MODE_SPARSE   1   /* ordering + supernodal block Cholesky on the whole Lambda */
+#define SPP_MODE_SCHUR    2   /* guided Schur complement (landmarks = smaller width) + dense reduced solve */
+
+/* spp_create flags */
+#define SPP_FLAG_PROFILE  1   /* record hipEvents around the phases of each solve */
+#define SPP_FLAG_SCHUR_PARTIAL 2 /* multi-GPU: spp_schur_form() leaves the partial S / rhs for an external all-reduce */
+
+typedef struct spp_ctx spp_ctx;
+
+/* ---- lifetime ---------------------------------------------------------------------------------
+ * replaces: CLinearSolver_UberBlock ctor / dtor / Free_Memory (LinearSolver_UberBlock.h:69-121) */
+spp_ctx *spp_create(int device, int flags);
+void spp_destroy(spp_ctx *ctx);
+/* drops factor/workspaces but keeps the ctx usable (Free_Memory, LinearSolver_UberBlock.h:88-121) */
+int spp_free_memory(spp_ctx *ctx);
+int spp_last_error(const spp_ctx *ctx, char *buf, size_t buf_size);
+/* run all work of this ctx on an externally owned hipStream_t (e.g. torch's current stream) */
+int spp_set_stream(spp_ctx *ctx, void *hip_stream);
+int spp_synchronize(spp_ctx *ctx);
+
+/* ---- symbolic -----------------------------------------------------------------------------------
+ * replaces: SymbolicDecomposition_Blocky (LinearSolver_UberBlock.h:272-296: block AMD ordering via
+ * OrderingMagic.cpp:701; LinearSolver_Schur.h:1566-1606: guided ordering) plus the structure-only
+ * work the reference redoes inside every Solve_PosDef_Blocky: Permute_UpperTriangular_To
+ * (BlockMatrix.cpp:8183), Build_EliminationTree (:9403), ereach (:9453), SliceTo/TransposeTo
+ * (LinearSolver_Schur.h:1699-1709). Call again whenever the block structure changes
+ * (Clear_SymbolicDecomposition, LinearSolver_UberBlock.h:260-264). */
+int spp_analyze(spp_ctx *ctx, int64_t nb, const int64_t *h_col_ptr, const int64_t *h_row_idx,
+	const int64_t *h_blk_off, const int32_t *h_dim, int mode);
+
+/* multi-GPU landmark sharding: this rank keeps only landmarks p with
+ * shard_of_landmark == rank; cameras and A are replicated. Call before spp_analyze. */
+int spp_set_shard(spp_ctx *ctx, int rank, int world_size);
+
+/* facts about the analyzed system; unknown keys give SPP_E_BADARG */
+#define SPP_INFO_MODE           0  /* SPP_MODE_SPARSE or SPP_MODE_SCHUR actually chosen */
+#define SPP_INFO_N              1  /* scalar dimension */
+#define SPP_INFO_NNZB           2  /* stored blocks of Lambda (upper incl. diagonal) */
+#define SPP_INFO_NVALS          3  /* doubles in vals */
+#define SPP_INFO_FACTOR_NNZ     4  /* scalar nonzeros of the factor (sparse) or n_reduced^2 storage (Schur dense) */
+#define SPP_INFO_FACTOR_FLOPS   5  /* flops of the numeric factorization */
+#define SPP_INFO_N_REDUCED      6  /* Schur: dimension of the reduced camera system */
+#define SPP_INFO_N_POSES        7
+#define SPP_INFO_N_LANDMARKS    8  /* landmarks owned by this shard */
+#define SPP_INFO_SCHUR_PAIRS    9  /* sum_p k_p (k_p+1)/2 block products of the S accumulation */
+#define SPP_INFO_N_OBS          10 /* pose-landmark blocks owned by this shard */
+#define SPP_INFO_SOLVE_BYTES    11 /* algorithmic HBM bytes of one numeric solve */
+#define SPP_INFO_N_SUPERNODES   12
+#define SPP_INFO_N_LEVELS       13
+#define SPP_INFO_S_LD           14 /* leading dimension of the dense S buffer (padded) */
+int spp_get_info(const spp_ctx *ctx, int what, int64_t *out);
+/* elimination order chosen by the analysis: order[k] = source block column eliminated k-th */
+int spp_get_ordering(const spp_ctx *ctx, int64_t *h_order);
+
+/* ---- numeric: host-pointer entry points (what the header adapter calls) ----------------------------
+ * replaces: Solve_PosDef_Blocky (LinearSolver_UberBlock.h:312-426; LinearSolver_Schur.h:1623-1935)
+ * and Solve_PosDef (LinearSolver_UberBlock.h:143-258). h_vals holds the blocks at the blk_off
+ * given to spp_analyze; h_rhs (length n) is overwritten with the solution. */
+int spp_factor_solve(spp_ctx *ctx, const double *h_vals, double *h_rhs_inout);
+
+/* ---- numeric: device-resident entry points (Lambda lives in HBM across GN iterations) ------------
+ * d_vals: nvals doubles in the layout given to spp_analyze; d_rhs: n doubles, in/out. */
+int spp_factor_solve_device(spp_ctx *ctx, const double *d_vals, double *d_rhs_inout);
+
+/* split form for multi-GPU: (1) each rank forms its partial Schur complement and
+ * reduced rhs into d_S_rhs = [S (ld x ld, column-major, upper blocks) | rhs (ld)] ; (2) the caller
+ * all-reduces that buffer (RCCL); (3) every rank factors S, solves and back-substitutes its own
+ * landmarks. With world_size == 1 step (2) is a no-op. rank 0 alone adds A and the pose rhs. */
+int spp_schur_buffer_size(const spp_ctx *ctx, int64_t *n_doubles);
+int spp_schur_form(spp_ctx *ctx, const double *d_vals, const double *d_rhs, double *d_S_rhs);
+int spp_schur_finish(spp_ctx *ctx, const double *d_vals, double *d_S_rhs, double *d_rhs_inout);
+
+/* ---- Lambda / eta assembly ------------------------------------------------------------------------
+ * replaces: CLambdaOps2::AddEntriesInSparseSystem + Alloc_HessianBlocks_v2 (symbolic;
+ * NonlinearSolver_Lambda_Base.h:1852-1931, BaseTypes_Binary.h:525-660) and Refresh_Lambda =
+ * Calculate_Hessians_v2 over all edges + ReduceAll (numeric; _Lambda_Base.h:1658-1688,
+ * BaseTypes_Binary.h:759-848, _Lambda_Base.h:563-607,152-197).
+ * One homogeneous binary-edge group: residual dimension rd, vertex 0 width d0, vertex 1 width d1.
+ * J0: ne x (rd x d0) col-major, J1: ne x (rd x d1), Omega: ne x (rd x rd), r: ne x rd.
+ * The unary factor (identity, FlatSystem.h:441,467) is added to the diagonal block of vertex
+ * `unary_vertex` (pass -1 for none); `damping` is added to every diagonal entry of Lambda
+ * (Levenberg-Marquardt, NonlinearSolver_Lambda_LM.h:228-239; 0 for Gauss-Newton). */
+int spp_assemble_analyze(spp_ctx *ctx, int64_t nv, const int32_t *h_dim,
+	int64_t ne, const int64_t *h_v0, const int64_t *h_v1, int d0, int d1, int rd,
+	int64_t unary_vertex);
+/* structure produced by spp_assemble_analyze (sizes via spp_get_info NNZB / NVALS) */
+int spp_assemble_get_structure(const spp_ctx *ctx, int64_t *h_col_ptr, int64_t *h_row_idx,
+	int64_t *h_blk_off);
+int spp_assemble_device(spp_ctx *ctx, const double *d_J0, const double *d_J1,
+	const double *d_Omega, const double *d_r, double damping, double *d_vals_out, double *d_eta_out);
+
+/* ---- device memory helpers for hosts without a HIP runtime of their own ---------------------------- */
+int spp_device_malloc(spp_ctx *ctx, size_t bytes, void **d_ptr);
+int spp_device_free(spp_ctx *ctx, void *d_ptr);
+int spp_memcpy_h2d(spp_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int spp_memcpy_d2h(spp_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+
+/* ---- profiling (SPP_FLAG_PROFILE) ------------------------------------------------------------------
+ * phase names follow the reference's __SCHUR_PROFILING / Dump() vocabulary
+ * (LinearSolver_Schur.h:1889-1912, NonlinearSolver_Lambda.h:250-276). */
+#define SPP_PHASE_PERMUTE   0
+#define SPP_PHASE_SCHUR_INV 1  /* C^-1 and W = -U C^-1 */
+#define SPP_PHASE_SCHUR_GEMM 2 /* S = A + W U^T */
+#define SPP_PHASE_SCHUR_RHS 3
+#define SPP_PHASE_FACTOR    4  /* numeric Cholesky (dense or sparse) */
+#define SPP_PHASE_TRISOLVE  5
+#define SPP_PHASE_BACKSUBST 6  /* landmark back-substitution */
+#define SPP_PHASE_ASSEMBLE  7
+#define SPP_PHASE_TOTAL     8
+#define SPP_N_PHASES        9
+/* milliseconds of each phase of the LAST solve / assemble call (hipEvent elapsed on the ctx stream) */
+int spp_get_phase_ms(spp_ctx *ctx, double *ms_out /* [SPP_N_PHASES] */);
+/* hipEvent-timed average duration (ms) of the dominant kernel family of the last solve:
+ * the MFMA trailing-update GEMM launches of the dense factor; n_launches/flops are totals */
+int spp_get_dominant_kernel(spp_ctx *ctx, double *ms_total, int64_t *n_launches, double *flops);
+
+/* ---- micro-benchmarks used by bench.py to report measured peaks beside the spec peaks ------------ */
+int spp_microbench_copy(spp_ctx *ctx, size_t bytes, int iters, double *gb_per_s);
+int spp_microbench_mfma_f64(spp_ctx *ctx, int iters, double *tflops);
+
+/* direct access to the dense kernels for unit tests (device pointers; A is n x n col-major, ld) */
+int spp_dense_potrf_upper(spp_ctx *ctx, double *d_A, int64_t n, int64_t ld);
+/* A x = b by the dense path (upper triangle of A read; A <- R, b <- x) */
+int spp_dense_posv(spp_ctx *ctx, double *d_A, int64_t n, int64_t ld, double *d_b);
+/* C (m x n, ldc) -= A^T B with A: k x m (lda), B: k x n (ldb): the MFMA trailing-update kernel */
+int spp_dense_gemm_tn_sub(spp_ctx *ctx, int64_t m, int64_t n, int64_t k,
+	const double *d_A, int64_t lda, const double *d_B, int64_t ldb, double *d_C, int64_t ldc);
+
+const char *spp_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPP_HIP_H */

@@ -1,0 +1,236 @@
+/*
+ * oracle/ref_driver.cpp -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * A thin extern "C" driver that feeds flat block-CSC arrays (the layout of
+ * include/spp_hip.h) into the *reference's own* linear solvers, compiled from
+ * the reference sources where they lie under /root/reference by
+ * oracle/Makefile (outputs only into oracle/_ref/). It exists so that
+ *   (1) the CPU restatement in oracle/spp_oracle.c can be pinned against the
+ *       reference itself (tests/test_oracle_vs_ref.py), and
+ *   (2) bench.py can time the reference CPU path beside the HIP path
+ *       (cpu_baseline.kind == "reference").
+ * Nothing here is copied from the reference: it only *calls* its public API
+ *   CUberBlockMatrix ctor(cumsums)           include/slam/BlockMatrix.h:180
+ *   CUberBlockMatrix::p_FindBlock            include/slam/BlockMatrix.h:1118
+ *   CLinearSolver_UberBlock                  include/slam/LinearSolver_UberBlock.h:44,312
+ *   CLinearSolver_CSparse                    include/slam/LinearSolver_CSparse.h:49,189
+ *   CLinearSolver_CholMod                    include/slam/LinearSolver_CholMod.h:194
+ *   CLinearSolver_Schur                      include/slam/LinearSolver_Schur.h:1423,1623
+ *   CMatrixOrdering::p_BlockOrdering         include/slam/OrderingMagic.h (cpp:701)
+ */
+#include <stdio.h>
+#include <string.h>
+#include <stdint.h>
+#include <time.h>
+#include <vector>
+#include <stdexcept>
+
+#include "slam/LinearSolver_UberBlock.h"
+#include "slam/LinearSolver_CSparse.h"
+#include "slam/LinearSolver_CholMod.h"
+#include "slam/ConfigSolvers.h"
+#include "slam/SE2_Types.h"
+#include "slam/SE3_Types.h"
+#include "slam/BA_Types.h"
+#include "slam/LinearSolver_Schur.h"
+#include "slam/OrderingMagic.h"
+
+namespace {
+
+typedef MakeTypelist_Safe((Eigen::Matrix3d)) TBlocks_SE2;
+typedef MakeTypelist_Safe((Eigen::Matrix<double, 6, 6>)) TBlocks_SE3;
+
+typedef MakeTypelist_Safe((CVertexCam, CVertexXYZ)) TBAVertexTypelist;
+typedef MakeTypelist_Safe((CEdgeP2C3D)) TBAEdgeTypelist;
+typedef CFlatSystem<CBaseVertex, TBAVertexTypelist, CEdgeP2C3D, TBAEdgeTypelist> CBASystem;
+typedef CBASystem::_TyHessianMatrixBlockList TBlocks_BA;
+
+typedef CLinearSolver_UberBlock<TBlocks_SE2> CUber_SE2;
+typedef CLinearSolver_UberBlock<TBlocks_SE3> CUber_SE3;
+typedef CLinearSolver_UberBlock<TBlocks_BA> CUber_BA;
+typedef CLinearSolver_Schur<CUber_BA, TBlocks_BA, CBASystem> CSchur_BA;
+
+double now_s()
+{
+	timespec t;
+	clock_gettime(CLOCK_MONOTONIC, &t);
+	return t.tv_sec + 1e-9 * t.tv_nsec;
+}
+
+struct TRef {
+	int backend, problem;
+	int64_t nb, n;
+	std::vector<int64_t> col_ptr, row_idx, base;
+	std::vector<int32_t> dim;
+	CUberBlockMatrix lambda;
+	std::vector<double*> blk_ptr; // pointer into lambda's pool for each stored block
+	CUber_SE2 uber2;
+	CUber_SE3 uber3;
+	CUber_BA uberba;
+	CLinearSolver_CSparse csparse;
+	CLinearSolver_CholMod cholmod;
+	CSchur_BA schur;
+	bool first;
+	TRef() : schur(CUber_BA()), first(true) {}
+};
+
+} // namespace
+
+extern "C" {
+
+/* backend: 0 UberBlock (FBS blocky), 1 CSparse (blocky), 2 CHOLMOD (Solve_PosDef, the
+ * elementwise entry NonlinearSolver_Lambda uses for it), 3 Schur<UberBlock> with the default
+ * dense Eigen LLT reduced solve (BA only).  problem: 0 SE2 (3x3), 1 SE3 (6x6), 2 BA (6/3). */
+void *ref_create(int backend, int problem)
+{
+	try {
+		TRef *p = new TRef;
+		p->backend = backend;
+		p->problem = problem;
+		return p;
+	} catch(std::exception &) {
+		return 0;
+	}
+}
+
+void ref_destroy(void *h)
+{
+	delete (TRef*)h;
+}
+
+/* upper-triangular block pattern, column-compressed, rows sorted ascending in each column */
+int ref_set_structure(void *h, int64_t nb, const int64_t *col_ptr,
+	const int64_t *row_idx, const int32_t *dim)
+{
+	TRef &r = *(TRef*)h;
+	try {
+		r.nb = nb;
+		r.col_ptr.assign(col_ptr, col_ptr + nb + 1);
+		r.row_idx.assign(row_idx, row_idx + col_ptr[nb]);
+		r.dim.assign(dim, dim + nb);
+		r.base.resize(nb + 1);
+		std::vector<size_t> cumsum(nb);
+		r.base[0] = 0;
+		for(int64_t i = 0; i < nb; ++ i) {
+			r.base[i + 1] = r.base[i] + dim[i];
+			cumsum[i] = size_t(r.base[i + 1]);
+		}
+		r.n = r.base[nb];
+		CUberBlockMatrix fresh(cumsum.begin(), cumsum.end(), cumsum.begin(), cumsum.end());
+		r.lambda.Swap(fresh);
+		r.blk_ptr.resize(col_ptr[nb]);
+		for(int64_t j = 0; j < nb; ++ j) {
+			for(int64_t p = col_ptr[j]; p < col_ptr[j + 1]; ++ p) {
+				int64_t i = row_idx[p];
+				double *b = r.lambda.p_FindBlock(size_t(r.base[i]), size_t(r.base[j]),
+					size_t(dim[i]), size_t(dim[j]), true, true);
+				if(!b)
+					return -1;
+				r.blk_ptr[p] = b;
+			}
+		}
+		r.first = true;
+		return 0;
+	} catch(std::exception &) {
+		return -2;
+	}
+}
+
+/* vals: dense column-major blocks, block p at vals + blk_off[p]; rhs overwritten by the
+ * solution. Returns 0 ok, 1 factorization failed (not SPD), <0 error. *seconds = wall time of
+ * the solver call only (value upload excluded). */
+int ref_solve(void *h, const double *vals, const int64_t *blk_off, double *rhs, double *seconds)
+{
+	TRef &r = *(TRef*)h;
+	try {
+		for(int64_t j = 0; j < r.nb; ++ j) {
+			for(int64_t p = r.col_ptr[j]; p < r.col_ptr[j + 1]; ++ p) {
+				size_t cnt = size_t(r.dim[r.row_idx[p]]) * size_t(r.dim[j]);
+				memcpy(r.blk_ptr[p], vals + blk_off[p], cnt * sizeof(double));
+			}
+		}
+		Eigen::VectorXd eta = Eigen::Map<const Eigen::VectorXd>(rhs, r.n);
+		bool ok = false;
+		double t0 = now_s();
+		switch(r.backend) {
+		case 0:
+			if(r.problem == 0) {
+				if(r.first) r.uber2.Clear_SymbolicDecomposition();
+				ok = r.uber2.Solve_PosDef_Blocky(r.lambda, eta);
+			} else if(r.problem == 1) {
+				if(r.first) r.uber3.Clear_SymbolicDecomposition();
+				ok = r.uber3.Solve_PosDef_Blocky(r.lambda, eta);
+			} else {
+				if(r.first) r.uberba.Clear_SymbolicDecomposition();
+				ok = r.uberba.Solve_PosDef_Blocky(r.lambda, eta);
+			}
+			break;
+		case 1:
+			if(r.first) r.csparse.Clear_SymbolicDecomposition();
+			ok = r.csparse.Solve_PosDef_Blocky(r.lambda, eta);
+			break;
+		case 2:
+			ok = r.cholmod.Solve_PosDef(r.lambda, eta);
+			break;
+		case 3:
+			if(r.problem != 2)
+				return -3;
+			if(r.first) r.schur.SymbolicDecomposition_Blocky(r.lambda);
+			ok = r.schur.Solve_PosDef_Blocky(r.lambda, eta);
+			break;
+		default:
+			return -4;
+		}
+		double t1 = now_s();
+		r.first = false;
+		if(seconds)
+			*seconds = t1 - t0;
+		if(!ok)
+			return 1;
+		memcpy(rhs, eta.data(), r.n * sizeof(double));
+		return 0;
+	} catch(std::bad_alloc &) {
+		return -5;
+	} catch(std::exception &) {
+		return -6;
+	}
+}
+
+/* the reference's block AMD ordering of the current structure (OrderingMagic.cpp:701):
+ * out_order[k] = source block column that is eliminated k-th */
+int ref_block_ordering(void *h, int64_t *out_order)
+{
+	TRef &r = *(TRef*)h;
+	try {
+		CMatrixOrdering mord;
+		const size_t *p = mord.p_BlockOrdering(r.lambda, true);
+		for(int64_t i = 0; i < r.nb; ++ i)
+			out_order[i] = int64_t(p[i]);
+		return 0;
+	} catch(std::exception &) {
+		return -1;
+	}
+}
+
+/* number of stored blocks / scalar nonzeros of the reference's R = chol(P Lambda P^T) under its
+ * own AMD ordering (fill comparison for the product's ordering code) */
+int ref_factor_fill(void *h, int64_t *out_nnzb, int64_t *out_nnz)
+{
+	TRef &r = *(TRef*)h;
+	try {
+		CMatrixOrdering mord;
+		mord.p_BlockOrdering(r.lambda, true);
+		const size_t *inv = mord.p_Get_InverseOrdering();
+		CUberBlockMatrix perm, R;
+		r.lambda.Permute_UpperTriangular_To(perm, inv, size_t(r.nb), true);
+		if(!R.CholeskyOf(perm))
+			return 1;
+		*out_nnzb = int64_t(R.n_Block_Num());
+		*out_nnz = int64_t(R.n_NonZero_Num());
+		return 0;
+	} catch(std::exception &) {
+		return -1;
+	}
+}
+
+} // extern "C"

@@ -1,0 +1,567 @@
+// spp_api.cpp -- the extern "C" boundary of libspp_hip.so (include/spp_hip.h) and the ctx plumbing.
+// No compute happens here; every numeric entry point ends in a HIP kernel launch on ctx->stream
+// and fails loudly (SPP_E_NO_DEVICE / SPP_E_HIP) when there is no usable gfx950 device.
+
+#include "spp_internal.h"
+#include <string.h>
+#include <new>
+
+using namespace spp;
+
+namespace spp {
+
+void phases_reset(spp_ctx *ctx)
+{
+	if(!(ctx->flags & SPP_FLAG_PROFILE))
+		return;
+	if(!ctx->timer.created) {
+		for(int i = 0; i < 2 * SPP_N_PHASES; ++ i)
+			SPP_HIP_CHECK(hipEventCreate(&ctx->timer.ev[i]));
+		ctx->timer.created = true;
+	}
+	for(int i = 0; i < SPP_N_PHASES; ++ i) {
+		ctx->timer.used[i] = false;
+		ctx->phase_ms[i] = 0;
+	}
+	ctx->dom_used = 0;
+	ctx->dom_flops = 0;
+}
+
+void phase_begin(spp_ctx *ctx, int phase)
+{
+	if(!(ctx->flags & SPP_FLAG_PROFILE) || !ctx->timer.created)
+		return;
+	SPP_HIP_CHECK(hipEventRecord(ctx->timer.ev[2 * phase], ctx->stream));
+}
+
+void phase_end(spp_ctx *ctx, int phase)
+{
+	if(!(ctx->flags & SPP_FLAG_PROFILE) || !ctx->timer.created)
+		return;
+	SPP_HIP_CHECK(hipEventRecord(ctx->timer.ev[2 * phase + 1], ctx->stream));
+	ctx->timer.used[phase] = true;
+}
+
+void phases_collect(spp_ctx *ctx)
+{
+	if(!(ctx->flags & SPP_FLAG_PROFILE) || !ctx->timer.created)
+		return;
+	SPP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	for(int i = 0; i < SPP_N_PHASES; ++ i) {
+		if(!ctx->timer.used[i])
+			continue;
+		float ms = 0;
+		if(hipEventElapsedTime(&ms, ctx->timer.ev[2 * i], ctx->timer.ev[2 * i + 1]) == hipSuccess)
+			ctx->phase_ms[i] = ms;
+	}
+}
+
+void dom_begin(spp_ctx *ctx)
+{
+	if(!(ctx->flags & SPP_FLAG_PROFILE))
+		return;
+	if(ctx->dom_used + 2 > ctx->dom_events.size()) {
+		size_t old = ctx->dom_events.size();
+		ctx->dom_events.resize(old + 64);
+		for(size_t i = old; i < ctx->dom_events.size(); ++ i)
+			SPP_HIP_CHECK(hipEventCreate(&ctx->dom_events[i]));
+	}
+	SPP_HIP_CHECK(hipEventRecord(ctx->dom_events[ctx->dom_used], ctx->stream));
+}
+
+void dom_end(spp_ctx *ctx, double flops)
+{
+	if(!(ctx->flags & SPP_FLAG_PROFILE))
+		return;
+	SPP_HIP_CHECK(hipEventRecord(ctx->dom_events[ctx->dom_used + 1], ctx->stream));
+	ctx->dom_used += 2;
+	ctx->dom_flops += flops;
+}
+
+} // namespace spp
+
+#define SPP_TRY(ctx) try {
+#define SPP_CATCH(ctx) } catch(const spp::Error &e) { if(ctx) (ctx)->last_error = e.what(); return e.code; } \
+	catch(const std::bad_alloc &) { if(ctx) (ctx)->last_error = "host allocation failed"; return SPP_E_NOMEM; } \
+	catch(const std::exception &e) { if(ctx) (ctx)->last_error = e.what(); return SPP_E_HIP; }
+
+extern "C" {
+
+const char *spp_version(void)
+{
+	return "slam_plus_plus_amd 0.1 (gfx950, fp64)";
+}
+
+spp_ctx *spp_create(int device, int flags)
+{
+	int count = 0;
+	if(hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count)
+		return nullptr; // no CPU fallback: the adapter turns this into std::runtime_error
+	if(hipSetDevice(device) != hipSuccess)
+		return nullptr;
+	spp_ctx *ctx = new(std::nothrow) spp_ctx;
+	if(!ctx)
+		return nullptr;
+	ctx->device = device;
+	ctx->flags = flags;
+	if(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+		delete ctx;
+		return nullptr;
+	}
+	ctx->own_stream = true;
+	return ctx;
+}
+
+int spp_free_memory(spp_ctx *ctx)
+{
+	if(!ctx)
+		return SPP_E_BADARG;
+	SPP_TRY(ctx)
+	(void)hipSetDevice(ctx->device);
+	(void)hipStreamSynchronize(ctx->stream);
+	ctx->schur.release_all();
+	sparse_release(ctx);
+	assemble_release(ctx);
+	ctx->dense.tinv.release();
+	ctx->dense.tinv_all.release();
+	ctx->dense.xtmp.release();
+	ctx->d_vals.release();
+	ctx->d_rhs.release();
+	ctx->mode = -1;
+	return SPP_OK;
+	SPP_CATCH(ctx)
+}
+
+void spp_destroy(spp_ctx *ctx)
+{
+	if(!ctx)
+		return;
+	spp_free_memory(ctx);
+	ctx->dense.info.release();
+	if(ctx->timer.created)
+		for(int i = 0; i < 2 * SPP_N_PHASES; ++ i)
+			(void)hipEventDestroy(ctx->timer.ev[i]);
+	for(size_t i = 0; i < ctx->dom_events.size(); ++ i)
+		(void)hipEventDestroy(ctx->dom_events[i]);
+	if(ctx->own_stream && ctx->stream)
+		(void)hipStreamDestroy(ctx->stream);
+	delete ctx;
+}
+
+int spp_last_error(const spp_ctx *ctx, char *buf, size_t buf_size)
+{
+	if(!ctx || !buf || !buf_size)
+		return SPP_E_BADARG;
+	strncpy(buf, ctx->last_error.c_str(), buf_size - 1);
+	buf[buf_size - 1] = 0;
+	return SPP_OK;
+}
+
+int spp_set_stream(spp_ctx *ctx, void *hip_stream)
+{
+	if(!ctx)
+		return SPP_E_BADARG;
+	(void)hipStreamSynchronize(ctx->stream);
+	if(ctx->own_stream && ctx->stream)
+		(void)hipStreamDestroy(ctx->stream);
+	ctx->stream = (hipStream_t)hip_stream;
+	ctx->own_stream = false;
+	return SPP_OK;
+}
+
+int spp_synchronize(spp_ctx *ctx)
+{
+	if(!ctx)
+		return SPP_E_BADARG;
+	SPP_TRY(ctx)
+	SPP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	return SPP_OK;
+	SPP_CATCH(ctx)
+}
+
+int spp_set_shard(spp_ctx *ctx, int rank, int world_size)
+{
+	if(!ctx || world_size < 1 || rank < 0 || rank >= world_size)
+		return SPP_E_BADARG;
+	ctx->shard_rank = rank;
+	ctx->shard_world = world_size;
+	return SPP_OK;
+}
+
+int spp_analyze(spp_ctx *ctx, int64_t nb, const int64_t *col_ptr, const int64_t *row_idx,
+	const int64_t *blk_off, const int32_t *dim, int mode)
+{
+	if(!ctx)
+		return SPP_E_BADARG;
+	SPP_TRY(ctx)
+	SPP_REQUIRE(nb > 0 && col_ptr && row_idx && blk_off && dim, SPP_E_BADARG, "spp_analyze: null or empty structure");
+	SPP_HIP_CHECK(hipSetDevice(ctx->device));
+	Structure &st = ctx->st;
+	st.nb = nb;
+	st.nnzb = col_ptr[nb];
+	st.col_ptr.assign(col_ptr, col_ptr + nb + 1);
+	st.row_idx.assign(row_idx, row_idx + st.nnzb);
+	st.blk_off.assign(blk_off, blk_off + st.nnzb);
+	st.dim.assign(dim, dim + nb);
+	st.base.resize(nb + 1);
+	st.base[0] = 0;
+	for(int64_t j = 0; j < nb; ++ j) {
+		SPP_REQUIRE(dim[j] > 0 && dim[j] <= 6, SPP_E_BADARG, "block widths must be in 1..6");
+		st.base[j + 1] = st.base[j] + dim[j];
+	}
+	st.n = st.base[nb];
+	st.nvals = 0;
+	for(int64_t j = 0; j < nb; ++ j) {
+		SPP_REQUIRE(col_ptr[j + 1] > col_ptr[j], SPP_E_BADARG, "every block column needs its diagonal block");
+		for(int64_t p = col_ptr[j]; p < col_ptr[j + 1]; ++ p) {
+			const int64_t i = row_idx[p];
+			SPP_REQUIRE(i >= 0 && i <= j, SPP_E_BADARG, "only the upper triangle may be stored");
+			SPP_REQUIRE(p == col_ptr[j] || row_idx[p - 1] < i, SPP_E_BADARG, "rows must ascend within a column");
+			SPP_REQUIRE(blk_off[p] >= 0, SPP_E_BADARG, "negative block offset");
+			st.nvals = std::max<int64_t>(st.nvals, blk_off[p] + (int64_t)dim[i] * dim[j]);
+		}
+		SPP_REQUIRE(row_idx[col_ptr[j + 1] - 1] == j, SPP_E_BADARG, "diagonal block missing (must be last in its column)");
+	}
+	ctx->schur.release_all();
+	sparse_release(ctx);
+	int dp, dl;
+	int chosen = mode;
+	if(mode == SPP_MODE_AUTO)
+		chosen = schur_applicable(st, &dp, &dl) ? SPP_MODE_SCHUR : SPP_MODE_SPARSE;
+	SPP_REQUIRE(chosen == SPP_MODE_SCHUR || chosen == SPP_MODE_SPARSE, SPP_E_BADARG, "unknown mode");
+	SPP_REQUIRE(chosen == SPP_MODE_SCHUR || ctx->shard_world == 1, SPP_E_UNSUPPORTED,
+		"sparse mode does not shard: replicas only (DESIGN.md, multi-GPU)");
+	ctx->mode = -1;
+	if(chosen == SPP_MODE_SCHUR) {
+		build_schur_plan(ctx);
+		ctx->order.clear();
+		for(size_t i = 0; i < ctx->schur.pose_block.size(); ++ i)
+			ctx->order.push_back(ctx->schur.pose_block[i]);
+		// landmarks are eliminated FIRST in elimination terms; the reference lists them last in its
+		// guided ordering (poses | landmarks), which is what order[] reports
+		for(int64_t j = 0; j < st.nb; ++ j)
+			if(st.dim[j] == ctx->schur.dl)
+				ctx->order.push_back(j);
+	} else
+		sparse_analyze(ctx);
+	ctx->mode = chosen;
+	return SPP_OK;
+	SPP_CATCH(ctx)
+}
+
+int spp_get_info(const spp_ctx *ctx, int what, int64_t *out)
+{
+	if(!ctx || !out)
+		return SPP_E_BADARG;
+	if(ctx->mode < 0 && what != SPP_INFO_NNZB && what != SPP_INFO_NVALS && what != SPP_INFO_N)
+		return SPP_E_STATE;
+	switch(what) {
+	case SPP_INFO_MODE: *out = ctx->mode; break;
+	case SPP_INFO_N: *out = ctx->st.n; break;
+	case SPP_INFO_NNZB: *out = ctx->st.nnzb; break;
+	case SPP_INFO_NVALS: *out = ctx->st.nvals; break;
+	case SPP_INFO_FACTOR_NNZ: *out = ctx->factor_nnz; break;
+	case SPP_INFO_FACTOR_FLOPS: *out = ctx->factor_flops; break;
+	case SPP_INFO_N_REDUCED: *out = (ctx->mode == SPP_MODE_SCHUR) ? ctx->schur.n_red : 0; break;
+	case SPP_INFO_N_POSES: *out = (ctx->mode == SPP_MODE_SCHUR) ? ctx->schur.nc : ctx->st.nb; break;
+	case SPP_INFO_N_LANDMARKS: *out = (ctx->mode == SPP_MODE_SCHUR) ? ctx->schur.nl : 0; break;
+	case SPP_INFO_SCHUR_PAIRS: *out = (ctx->mode == SPP_MODE_SCHUR) ? ctx->schur.n_pairs : 0; break;
+	case SPP_INFO_N_OBS: *out = (ctx->mode == SPP_MODE_SCHUR) ? ctx->schur.no : 0; break;
+	case SPP_INFO_SOLVE_BYTES: *out = ctx->solve_bytes; break;
+	case SPP_INFO_N_SUPERNODES: *out = (ctx->mode == SPP_MODE_SPARSE) ? sparse_info(ctx, what) : 0; break;
+	case SPP_INFO_N_LEVELS: *out = (ctx->mode == SPP_MODE_SPARSE) ? sparse_info(ctx, what) : 0; break;
+	case SPP_INFO_S_LD: *out = (ctx->mode == SPP_MODE_SCHUR) ? ctx->schur.ld : 0; break;
+	default: return SPP_E_BADARG;
+	}
+	return SPP_OK;
+}
+
+int spp_get_ordering(const spp_ctx *ctx, int64_t *h_order)
+{
+	if(!ctx || !h_order)
+		return SPP_E_BADARG;
+	if(ctx->mode < 0)
+		return SPP_E_STATE;
+	for(size_t i = 0; i < ctx->order.size(); ++ i)
+		h_order[i] = ctx->order[i];
+	return SPP_OK;
+}
+
+int spp_schur_buffer_size(const spp_ctx *ctx, int64_t *n_doubles)
+{
+	if(!ctx || !n_doubles)
+		return SPP_E_BADARG;
+	if(ctx->mode != SPP_MODE_SCHUR)
+		return SPP_E_STATE;
+	*n_doubles = ctx->schur.ld * ctx->schur.ld;
+	return SPP_OK;
+}
+
+int spp_schur_form(spp_ctx *ctx, const double *d_vals, const double *d_rhs, double *d_S_rhs)
+{
+	if(!ctx || !d_vals || !d_rhs || !d_S_rhs)
+		return SPP_E_BADARG;
+	SPP_TRY(ctx)
+	SPP_REQUIRE(ctx->mode == SPP_MODE_SCHUR, SPP_E_STATE, "spp_schur_form: analyze in Schur mode first");
+	SPP_HIP_CHECK(hipSetDevice(ctx->device));
+	phases_reset(ctx);
+	phase_begin(ctx, SPP_PHASE_TOTAL);
+	schur_form(ctx, d_vals, d_rhs, d_S_rhs);
+	return SPP_OK;
+	SPP_CATCH(ctx)
+}
+
+int spp_schur_finish(spp_ctx *ctx, const double *d_vals, double *d_S_rhs, double *d_rhs_inout)
+{
+	if(!ctx || !d_vals || !d_rhs_inout || !d_S_rhs)
+		return SPP_E_BADARG;
+	SPP_TRY(ctx)
+	SPP_REQUIRE(ctx->mode == SPP_MODE_SCHUR, SPP_E_STATE, "spp_schur_finish: analyze in Schur mode first");
+	SPP_HIP_CHECK(hipSetDevice(ctx->device));
+	int ret = schur_finish(ctx, d_vals, d_S_rhs, d_rhs_inout);
+	phase_end(ctx, SPP_PHASE_TOTAL);
+	phases_collect(ctx);
+	return ret;
+	SPP_CATCH(ctx)
+}
+
+int spp_factor_solve_device(spp_ctx *ctx, const double *d_vals, double *d_rhs)
+{
+	if(!ctx || !d_vals || !d_rhs)
+		return SPP_E_BADARG;
+	SPP_TRY(ctx)
+	SPP_REQUIRE(ctx->mode >= 0, SPP_E_STATE, "spp_factor_solve: call spp_analyze first");
+	SPP_HIP_CHECK(hipSetDevice(ctx->device));
+	phases_reset(ctx);
+	phase_begin(ctx, SPP_PHASE_TOTAL);
+	int ret;
+	if(ctx->mode == SPP_MODE_SCHUR) {
+		SPP_REQUIRE(ctx->shard_world == 1, SPP_E_STATE,
+			"sharded ctx: use spp_schur_form / all-reduce / spp_schur_finish");
+		ctx->schur.S.reserve((size_t)ctx->schur.ld * ctx->schur.ld);
+		schur_form(ctx, d_vals, d_rhs, ctx->schur.S.p);
+		ret = schur_finish(ctx, d_vals, ctx->schur.S.p, d_rhs);
+	} else
+		ret = sparse_factor_solve(ctx, d_vals, d_rhs);
+	phase_end(ctx, SPP_PHASE_TOTAL);
+	phases_collect(ctx);
+	SPP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	return ret;
+	SPP_CATCH(ctx)
+}
+
+int spp_factor_solve(spp_ctx *ctx, const double *h_vals, double *h_rhs)
+{
+	if(!ctx || !h_vals || !h_rhs)
+		return SPP_E_BADARG;
+	SPP_TRY(ctx)
+	SPP_REQUIRE(ctx->mode >= 0, SPP_E_STATE, "spp_factor_solve: call spp_analyze first");
+	SPP_HIP_CHECK(hipSetDevice(ctx->device));
+	ctx->d_vals.reserve((size_t)ctx->st.nvals);
+	ctx->d_rhs.reserve((size_t)ctx->st.n);
+	SPP_HIP_CHECK(hipMemcpyAsync(ctx->d_vals.p, h_vals, ctx->st.nvals * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+	SPP_HIP_CHECK(hipMemcpyAsync(ctx->d_rhs.p, h_rhs, ctx->st.n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+	int ret = spp_factor_solve_device(ctx, ctx->d_vals.p, ctx->d_rhs.p);
+	if(ret != SPP_OK)
+		return ret; // the rhs is left untouched on failure, like the reference (LinearSolver_UberBlock.h:411-423)
+	SPP_HIP_CHECK(hipMemcpyAsync(h_rhs, ctx->d_rhs.p, ctx->st.n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+	SPP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	return SPP_OK;
+	SPP_CATCH(ctx)
+}
+
+int spp_assemble_analyze(spp_ctx *ctx, int64_t nv, const int32_t *h_dim, int64_t ne, const int64_t *h_v0,
+	const int64_t *h_v1, int d0, int d1, int rd, int64_t unary_vertex)
+{
+	if(!ctx || !h_dim || !h_v0 || !h_v1 || nv <= 0 || ne <= 0)
+		return SPP_E_BADARG;
+	SPP_TRY(ctx)
+	SPP_HIP_CHECK(hipSetDevice(ctx->device));
+	assemble_analyze(ctx, nv, h_dim, ne, h_v0, h_v1, d0, d1, rd, unary_vertex);
+	return SPP_OK;
+	SPP_CATCH(ctx)
+}
+
+int spp_assemble_get_structure(const spp_ctx *ctx, int64_t *h_col_ptr, int64_t *h_row_idx, int64_t *h_blk_off)
+{
+	if(!ctx || !ctx->assemble)
+		return SPP_E_STATE;
+	assemble_get_structure(ctx, h_col_ptr, h_row_idx, h_blk_off);
+	return SPP_OK;
+}
+
+int spp_assemble_device(spp_ctx *ctx, const double *d_J0, const double *d_J1, const double *d_Omega,
+	const double *d_r, double damping, double *d_vals_out, double *d_eta_out)
+{
+	if(!ctx || !d_J0 || !d_J1 || !d_Omega || !d_r || !d_vals_out || !d_eta_out)
+		return SPP_E_BADARG;
+	SPP_TRY(ctx)
+	SPP_REQUIRE(ctx->assemble, SPP_E_STATE, "spp_assemble_device: call spp_assemble_analyze first");
+	SPP_HIP_CHECK(hipSetDevice(ctx->device));
+	phases_reset(ctx);
+	phase_begin(ctx, SPP_PHASE_ASSEMBLE);
+	assemble_run(ctx, d_J0, d_J1, d_Omega, d_r, damping, d_vals_out, d_eta_out);
+	phase_end(ctx, SPP_PHASE_ASSEMBLE);
+	phases_collect(ctx);
+	return SPP_OK;
+	SPP_CATCH(ctx)
+}
+
+int spp_device_malloc(spp_ctx *ctx, size_t bytes, void **d_ptr)
+{
+	if(!ctx || !d_ptr)
+		return SPP_E_BADARG;
+	(void)hipSetDevice(ctx->device);
+	if(hipMalloc(d_ptr, bytes ? bytes : 8) != hipSuccess) {
+		ctx->last_error = "hipMalloc failed";
+		return SPP_E_NOMEM;
+	}
+	return SPP_OK;
+}
+
+int spp_device_free(spp_ctx *ctx, void *d_ptr)
+{
+	if(!ctx)
+		return SPP_E_BADARG;
+	(void)hipSetDevice(ctx->device);
+	(void)hipStreamSynchronize(ctx->stream);
+	return hipFree(d_ptr) == hipSuccess ? SPP_OK : SPP_E_HIP;
+}
+
+int spp_memcpy_h2d(spp_ctx *ctx, void *d_dst, const void *h_src, size_t bytes)
+{
+	if(!ctx)
+		return SPP_E_BADARG;
+	SPP_TRY(ctx)
+	SPP_HIP_CHECK(hipSetDevice(ctx->device));
+	SPP_HIP_CHECK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+	SPP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	return SPP_OK;
+	SPP_CATCH(ctx)
+}
+
+int spp_memcpy_d2h(spp_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)
+{
+	if(!ctx)
+		return SPP_E_BADARG;
+	SPP_TRY(ctx)
+	SPP_HIP_CHECK(hipSetDevice(ctx->device));
+	SPP_HIP_CHECK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+	SPP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	return SPP_OK;
+	SPP_CATCH(ctx)
+}
+
+int spp_get_phase_ms(spp_ctx *ctx, double *ms_out)
+{
+	if(!ctx || !ms_out)
+		return SPP_E_BADARG;
+	for(int i = 0; i < SPP_N_PHASES; ++ i)
+		ms_out[i] = ctx->phase_ms[i];
+	return SPP_OK;
+}
+
+int spp_get_dominant_kernel(spp_ctx *ctx, double *ms_total, int64_t *n_launches, double *flops)
+{
+	if(!ctx || !ms_total || !n_launches || !flops)
+		return SPP_E_BADARG;
+	SPP_TRY(ctx)
+	SPP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	double total = 0;
+	for(size_t i = 0; i + 1 < ctx->dom_used; i += 2) {
+		float ms = 0;
+		SPP_HIP_CHECK(hipEventElapsedTime(&ms, ctx->dom_events[i], ctx->dom_events[i + 1]));
+		total += ms;
+	}
+	*ms_total = total;
+	*n_launches = (int64_t)(ctx->dom_used / 2);
+	*flops = ctx->dom_flops;
+	return SPP_OK;
+	SPP_CATCH(ctx)
+}
+
+int spp_microbench_copy(spp_ctx *ctx, size_t bytes, int iters, double *gb_per_s)
+{
+	if(!ctx || !gb_per_s)
+		return SPP_E_BADARG;
+	SPP_TRY(ctx)
+	SPP_HIP_CHECK(hipSetDevice(ctx->device));
+	*gb_per_s = microbench_copy(ctx, bytes, iters);
+	return SPP_OK;
+	SPP_CATCH(ctx)
+}
+
+int spp_microbench_mfma_f64(spp_ctx *ctx, int iters, double *tflops)
+{
+	if(!ctx || !tflops)
+		return SPP_E_BADARG;
+	SPP_TRY(ctx)
+	SPP_HIP_CHECK(hipSetDevice(ctx->device));
+	*tflops = microbench_mfma_f64(ctx, iters);
+	return SPP_OK;
+	SPP_CATCH(ctx)
+}
+
+// ---- dense kernels exposed for unit tests: arbitrary n, copies into a padded workspace ----------
+int spp_dense_potrf_upper(spp_ctx *ctx, double *d_A, int64_t n, int64_t ld)
+{
+	if(!ctx || !d_A || n <= 0 || ld < n)
+		return SPP_E_BADARG;
+	SPP_TRY(ctx)
+	SPP_HIP_CHECK(hipSetDevice(ctx->device));
+	const int64_t ldp = ((n + 1 + DENSE_NB - 1) / DENSE_NB) * DENSE_NB;
+	DevBuf<double> tmp;
+	tmp.reserve((size_t)ldp * ldp);
+	SPP_HIP_CHECK(hipMemsetAsync(tmp.p, 0, (size_t)ldp * ldp * sizeof(double), ctx->stream));
+	SPP_HIP_CHECK(hipMemcpy2DAsync(tmp.p, ldp * sizeof(double), d_A, ld * sizeof(double), n * sizeof(double), n,
+		hipMemcpyDeviceToDevice, ctx->stream));
+	dense_set_padding(ctx, tmp.p, ldp, n);
+	int ret = dense_potrf_upper(ctx, tmp.p, n, ldp, true);
+	SPP_HIP_CHECK(hipMemcpy2DAsync(d_A, ld * sizeof(double), tmp.p, ldp * sizeof(double), n * sizeof(double), n,
+		hipMemcpyDeviceToDevice, ctx->stream));
+	SPP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	return ret;
+	SPP_CATCH(ctx)
+}
+
+int spp_dense_posv(spp_ctx *ctx, double *d_A, int64_t n, int64_t ld, double *d_b)
+{
+	if(!ctx || !d_A || !d_b || n <= 0 || ld < n)
+		return SPP_E_BADARG;
+	SPP_TRY(ctx)
+	SPP_HIP_CHECK(hipSetDevice(ctx->device));
+	const int64_t ldp = ((n + 1 + DENSE_NB - 1) / DENSE_NB) * DENSE_NB;
+	DevBuf<double> tmp;
+	tmp.reserve((size_t)ldp * ldp);
+	SPP_HIP_CHECK(hipMemsetAsync(tmp.p, 0, (size_t)ldp * ldp * sizeof(double), ctx->stream));
+	SPP_HIP_CHECK(hipMemcpy2DAsync(tmp.p, ldp * sizeof(double), d_A, ld * sizeof(double), n * sizeof(double), n,
+		hipMemcpyDeviceToDevice, ctx->stream));
+	dense_set_padding(ctx, tmp.p, ldp, n);
+	SPP_HIP_CHECK(hipMemcpyAsync(tmp.p + n * ldp, d_b, n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+	int ret = dense_potrf_upper(ctx, tmp.p, n, ldp, true);
+	if(ret == SPP_OK) {
+		dense_potrs_upper(ctx, tmp.p, n, ldp, tmp.p + n * ldp);
+		SPP_HIP_CHECK(hipMemcpyAsync(d_b, tmp.p + n * ldp, n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+		SPP_HIP_CHECK(hipMemcpy2DAsync(d_A, ld * sizeof(double), tmp.p, ldp * sizeof(double), n * sizeof(double), n,
+			hipMemcpyDeviceToDevice, ctx->stream));
+	}
+	SPP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	return ret;
+	SPP_CATCH(ctx)
+}
+
+int spp_dense_gemm_tn_sub(spp_ctx *ctx, int64_t m, int64_t n, int64_t k, const double *d_A, int64_t lda,
+	const double *d_B, int64_t ldb, double *d_C, int64_t ldc)
+{
+	if(!ctx || !d_A || !d_B || !d_C)
+		return SPP_E_BADARG;
+	SPP_TRY(ctx)
+	SPP_REQUIRE((lda % 2) == 0 && (ldb % 2) == 0, SPP_E_BADARG, "gemm_tn_sub: lda/ldb must be even (16-byte loads)");
+	SPP_HIP_CHECK(hipSetDevice(ctx->device));
+	dense_gemm_tn_sub(ctx, m, n, k, d_A, lda, d_B, ldb, d_C, ldc, false);
+	SPP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	return SPP_OK;
+	SPP_CATCH(ctx)
+}
+
+} // extern "C"

@@ -1,0 +1,212 @@
+// spp_internal.h -- private declarations shared by the translation units of libspp_hip.so.
+// MI355X (gfx950) only: no CUDA shims, no CPU fallback. See include/spp_hip.h for the ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include <stdexcept>
+#include "../../include/spp_hip.h"
+
+namespace spp {
+
+// ------------------------------------------------------------------------------------------------
+// errors: internal code throws, the extern "C" layer converts to SPP_E_* codes
+// ------------------------------------------------------------------------------------------------
+struct Error : std::runtime_error {
+	int code;
+	Error(int c, const std::string &what) : std::runtime_error(what), code(c) {}
+};
+
+#define SPP_HIP_CHECK(expr) do { hipError_t e_ = (expr); if(e_ != hipSuccess) \
+	throw spp::Error(SPP_E_HIP, std::string(#expr " failed: ") + hipGetErrorString(e_)); } while(0)
+#define SPP_REQUIRE(cond, code, msg) do { if(!(cond)) throw spp::Error((code), (msg)); } while(0)
+
+// ------------------------------------------------------------------------------------------------
+// device buffer (owned, grows geometrically like the reference's workspaces,
+// LinearSolver_UberBlock.h:332-348)
+// ------------------------------------------------------------------------------------------------
+template <class T>
+struct DevBuf {
+	T *p = nullptr;
+	size_t cap = 0; // elements
+	DevBuf() {}
+	DevBuf(const DevBuf&) = delete;
+	DevBuf &operator=(const DevBuf&) = delete;
+	~DevBuf() { release(); }
+	void release() { if(p) { (void)hipFree(p); p = nullptr; cap = 0; } }
+	void reserve(size_t n)
+	{
+		if(n <= cap)
+			return;
+		release();
+		size_t want = n;
+		hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+		if(e != hipSuccess) {
+			p = nullptr;
+			throw Error(SPP_E_NOMEM, "hipMalloc of " + std::to_string(want * sizeof(T)) + " bytes failed");
+		}
+		cap = want;
+	}
+	void upload(const std::vector<T> &h, hipStream_t s)
+	{
+		reserve(h.size() ? h.size() : 1);
+		if(!h.empty())
+			SPP_HIP_CHECK(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
+	}
+};
+
+// ------------------------------------------------------------------------------------------------
+// host-side copy of the analyzed Lambda structure
+// ------------------------------------------------------------------------------------------------
+struct Structure {
+	int64_t nb = 0, n = 0, nnzb = 0, nvals = 0;
+	std::vector<int64_t> col_ptr, row_idx, blk_off, base;
+	std::vector<int32_t> dim;
+};
+
+// ------------------------------------------------------------------------------------------------
+// Schur plan (guided ordering: poses first, landmarks last; LinearSolver_Schur.cpp:771-838)
+// ------------------------------------------------------------------------------------------------
+struct SchurPlan {
+	int dp = 0, dl = 0;            // pose / landmark block width
+	int64_t nc = 0, nl = 0;        // poses, landmarks owned by this shard
+	int64_t nl_total = 0;
+	int64_t no = 0;                // pose-landmark blocks (observations) of this shard
+	int64_t n_red = 0, ld = 0;     // reduced dimension, padded leading dimension
+	int64_t n_sblk = 0;            // blocks of S that are written (upper, incl. diagonal)
+	int64_t n_pairs = 0;           // sum_p k_p (k_p + 1) / 2
+	int64_t n_items = 0, n_multi = 0; // work items (block chunks) / blocks split over several items
+	bool add_A = true;             // this shard adds A and the pose rhs (rank 0)
+	// host copies needed later
+	std::vector<int64_t> pose_block; // reduced pose index -> original block column
+	std::vector<int64_t> lm_block;   // owned landmark index -> original block column
+	// device arrays
+	DevBuf<int32_t> lm_ptr;        // [nl+1] first obs of landmark
+	DevBuf<int64_t> lm_coff;       // [nl] offset of C block in vals
+	DevBuf<int64_t> lm_rbase;      // [nl] scalar offset of the landmark in rhs
+	DevBuf<int32_t> obs_pose;      // [no] reduced pose index
+	DevBuf<int32_t> obs_lm;        // [no] owned landmark index
+	DevBuf<int64_t> obs_off;       // [no] (offset in vals << 1) | transposed
+	DevBuf<int64_t> pose_rbase;    // [nc] scalar offset of the pose in rhs
+	DevBuf<int32_t> cam_ptr;       // [nc+1] obs list per pose (ascending landmark)
+	DevBuf<int32_t> cam_obs;       // [no]
+	// S accumulation work items
+	DevBuf<int32_t> item_blk;      // [n_items] S block id
+	DevBuf<int32_t> item_beg;      // [n_items+1] pair range
+	DevBuf<int32_t> item_slot;     // [n_items] -1: writes S directly, else partial slot
+	DevBuf<int32_t> sblk_i1, sblk_i2; // [n_sblk]
+	DevBuf<int64_t> sblk_aoff;     // [n_sblk] offset of the A block in vals or -1
+	DevBuf<int32_t> pair_a, pair_b; // [n_pairs]
+	DevBuf<int32_t> multi_blk;     // [n_multi] S block id of split blocks
+	DevBuf<int32_t> multi_ptr;     // [n_multi+1] slot range
+	// numeric workspaces
+	DevBuf<double> cinv;           // [nl * dl*dl]   -(C^-1)
+	DevBuf<double> W;              // [no * dp*dl]   -U C^-1
+	DevBuf<double> Up;             // [no * dp*dl]   U packed in obs order
+	DevBuf<double> xw;             // [no * dp]      W l per observation
+	DevBuf<double> partial;        // [slots * dp*dp]
+	DevBuf<double> S;              // [ld*ld + ld] when the caller does not supply the buffer
+	void release_all();
+};
+
+// ------------------------------------------------------------------------------------------------
+// dense Cholesky workspace
+// ------------------------------------------------------------------------------------------------
+struct DenseWork {
+	DevBuf<double> tinv;           // inverse of the current diagonal block (NB x NB)
+	DevBuf<int> info;              // device flag: 0 ok, j+1 = pivot j non-positive
+	DevBuf<double> tinv_all;       // inverses of all diagonal blocks (nblk x NB x NB) kept for the solves
+	DevBuf<double> xtmp;           // solution of the backward substitution before it replaces y
+};
+
+// ------------------------------------------------------------------------------------------------
+// sparse (multifrontal supernodal) plan -- spp_sparse.hip / spp_symbolic.cpp
+// ------------------------------------------------------------------------------------------------
+struct SparsePlan;
+
+// ------------------------------------------------------------------------------------------------
+// assembly plan -- spp_assemble.hip
+// ------------------------------------------------------------------------------------------------
+struct AssemblePlan;
+
+struct PhaseTimer {
+	hipEvent_t ev[2 * SPP_N_PHASES];
+	bool used[SPP_N_PHASES];
+	bool created = false;
+};
+
+} // namespace spp
+
+struct spp_ctx {
+	int device = 0;
+	int flags = 0;
+	hipStream_t stream = nullptr;
+	bool own_stream = false;
+	std::string last_error;
+	int mode = -1; // -1: not analyzed
+	int shard_rank = 0, shard_world = 1;
+	spp::Structure st;
+	std::vector<int64_t> order; // elimination order (block columns)
+	spp::SchurPlan schur;
+	spp::DenseWork dense;
+	spp::SparsePlan *sparse = nullptr;
+	spp::AssemblePlan *assemble = nullptr;
+	// staging buffers for the host-pointer entry points
+	spp::DevBuf<double> d_vals, d_rhs;
+	// profiling
+	spp::PhaseTimer timer;
+	double phase_ms[SPP_N_PHASES] = {0};
+	// dominant-kernel accounting (MFMA trailing update)
+	std::vector<hipEvent_t> dom_events; // pairs
+	size_t dom_used = 0;
+	double dom_flops = 0;
+	int64_t factor_flops = 0, solve_bytes = 0, factor_nnz = 0;
+};
+
+namespace spp {
+
+// ---- spp_symbolic.cpp ----
+void min_degree_order(int64_t nb, const int64_t *col_ptr, const int64_t *row_idx, std::vector<int64_t> &order);
+void build_schur_plan(spp_ctx *ctx);
+bool schur_applicable(const Structure &st, int *dp, int *dl);
+
+// ---- spp_sparse (symbolic on host + numeric on device) ----
+void sparse_analyze(spp_ctx *ctx);
+int sparse_factor_solve(spp_ctx *ctx, const double *d_vals, double *d_rhs);
+void sparse_release(spp_ctx *ctx);
+int64_t sparse_info(const spp_ctx *ctx, int what);
+
+// ---- spp_schur.hip ----
+void schur_form(spp_ctx *ctx, const double *d_vals, const double *d_rhs, double *d_S_rhs);
+int schur_finish(spp_ctx *ctx, const double *d_vals, double *d_S_rhs, double *d_rhs);
+
+// ---- spp_dense.hip ----
+constexpr int DENSE_NB = 128;
+int dense_potrf_upper(spp_ctx *ctx, double *d_A, int64_t n, int64_t ld, bool keep_inverses);
+void dense_potrs_upper(spp_ctx *ctx, const double *d_R, int64_t n, int64_t ld, double *d_b);
+void dense_set_padding(spp_ctx *ctx, double *d_A, int64_t ld, int64_t n);
+void dense_gemm_tn_sub(spp_ctx *ctx, int64_t m, int64_t n, int64_t k, const double *A, int64_t lda,
+	const double *B, int64_t ldb, double *C, int64_t ldc, bool upper_only);
+double microbench_copy(spp_ctx *ctx, size_t bytes, int iters);
+double microbench_mfma_f64(spp_ctx *ctx, int iters);
+
+// ---- spp_assemble.hip ----
+void assemble_analyze(spp_ctx *ctx, int64_t nv, const int32_t *dim, int64_t ne, const int64_t *v0,
+	const int64_t *v1, int d0, int d1, int rd, int64_t unary_vertex);
+void assemble_run(spp_ctx *ctx, const double *J0, const double *J1, const double *Om, const double *r,
+	double damping, double *vals, double *eta);
+void assemble_release(spp_ctx *ctx);
+void assemble_get_structure(const spp_ctx *ctx, int64_t *col_ptr, int64_t *row_idx, int64_t *blk_off);
+
+// ---- profiling helpers (spp_api.cpp) ----
+void phase_begin(spp_ctx *ctx, int phase);
+void phase_end(spp_ctx *ctx, int phase);
+void phases_reset(spp_ctx *ctx);
+void phases_collect(spp_ctx *ctx);
+// dominant-kernel event bracket
+void dom_begin(spp_ctx *ctx);
+void dom_end(spp_ctx *ctx, double flops);
+
+} // namespace spp

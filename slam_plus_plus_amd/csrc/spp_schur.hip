@@ -1,0 +1,359 @@
+// spp_schur.hip -- landmark elimination (Schur complement) on gfx950, fp64.
+//
+// Replaces the numeric part of CLinearSolver_Schur::Solve_PosDef_Blocky
+// (reference include/slam/LinearSolver_Schur.h:1623-1935), phase by phase:
+//   cinv_kernel      C^-1 block by block, negated        :1721-1735  (InverseOf_BlockDiag_FBS_Parallel,
+//                                                         BlockMatrixFBS.inl:1750-1868; Eigen cofactor
+//                                                         inverse BlockMatrixBase.h:1257-1270; Scale(-1))
+//   obs_kernel       W = U * (-C^-1), W l                 :1737-1745 (MultiplyToWith_FBS #1), :1829
+//   s_accum_kernel   S = W * U^T (upper) + A              :1757-1767 (MultiplyToWith_FBS #2 + AddTo_FBS)
+//   rhs_kernel       x = eta_pose + sum W l               :1811-1830 (PreMultiply_Add_FBS)
+//   [dense LLT, spp_dense.hip]                            :1839-1853
+//   backsubst_kernel l = -l + U^T dx ; dl = (-C^-1) l     :1867-1881 (PostMultiply_Add_FBS_Parallel, PreMultiply_Add)
+// The reference's Permute_UpperTriangular_To / SliceTo / TransposeTo (:1688-1709) move no data here:
+// the kernels address the blocks of the ORIGINAL Lambda through the index lists built once by
+// build_schur_plan() (spp_symbolic.cpp).
+//
+// Accumulation order of S: the pair list of every S block is sorted by landmark, which is the
+// order in which the reference's product walks the columns of V; sums are sequential per output
+// element (no atomics) => bit-reproducible run to run, and order-identical to the reference for
+// blocks that are not split into chunks.
+//
+// Roofline: all kernels here are HBM/L2-bandwidth bound (0.25-1.5 flop/B); nothing is
+// reshaped into GEMMs.
+
+#include "spp_internal.h"
+
+namespace spp {
+
+// ---- -(C^-1), one thread per landmark -------------------------------------------------------------
+template <int DL>
+__global__ __launch_bounds__(256)
+void cinv_kernel(int64_t nl, const int64_t *__restrict__ lm_coff, const double *__restrict__ vals,
+	double *__restrict__ cinv)
+{
+	const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if(l >= nl)
+		return;
+	const double *m = vals + lm_coff[l];
+	double *o = cinv + l * DL * DL;
+	if(DL == 3) {
+		// cofactor formula with ONE reciprocal, determinant expanded along column 0
+		// (what Eigen's fixed-size 3x3 inverse evaluates)
+#define M_(i, j) m[(i) + 3 * (j)]
+#define COF_(i, j) (M_(((i) + 1) % 3, ((j) + 1) % 3) * M_(((i) + 2) % 3, ((j) + 2) % 3) - \
+	M_(((i) + 1) % 3, ((j) + 2) % 3) * M_(((i) + 2) % 3, ((j) + 1) % 3))
+		const double c00 = COF_(0, 0), c10 = COF_(1, 0), c20 = COF_(2, 0);
+		const double det = c00 * M_(0, 0) + c10 * M_(1, 0) + c20 * M_(2, 0);
+		const double id = -1.0 / det; // negated: Scale(-1), LinearSolver_Schur.h:1735
+		o[0] = c00 * id; o[3] = c10 * id; o[6] = c20 * id;
+		o[1] = COF_(0, 1) * id; o[4] = COF_(1, 1) * id; o[7] = COF_(2, 1) * id;
+		o[2] = COF_(0, 2) * id; o[5] = COF_(1, 2) * id; o[8] = COF_(2, 2) * id;
+#undef COF_
+#undef M_
+	} else { // DL == 2
+		const double det = m[0] * m[3] - m[2] * m[1];
+		const double id = -1.0 / det;
+		o[0] = m[3] * id; o[2] = -m[2] * id;
+		o[1] = -m[1] * id; o[3] = m[0] * id;
+	}
+}
+
+// ---- W = U (-C^-1), packed U, W l : one thread per observation ------------------------------------
+template <int DP, int DL>
+__global__ __launch_bounds__(256)
+void obs_kernel(int64_t no, const int32_t *__restrict__ obs_lm, const int64_t *__restrict__ obs_off,
+	const int64_t *__restrict__ lm_rbase, const double *__restrict__ vals, const double *__restrict__ rhs,
+	const double *__restrict__ cinv, double *__restrict__ W, double *__restrict__ Up, double *__restrict__ xw)
+{
+	const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if(a >= no)
+		return;
+	const int32_t l = obs_lm[a];
+	const int64_t oo = obs_off[a];
+	const double *src = vals + (oo >> 1);
+	double U[DP * DL];
+	if(oo & 1) { // stored transposed (landmark id < pose id): DL x DP column-major
+#pragma unroll
+		for(int r = 0; r < DP; ++ r)
+#pragma unroll
+			for(int q = 0; q < DL; ++ q)
+				U[r + DP * q] = src[q + DL * r];
+	} else {
+#pragma unroll
+		for(int e = 0; e < DP * DL; ++ e)
+			U[e] = src[e];
+	}
+	double Ci[DL * DL];
+#pragma unroll
+	for(int e = 0; e < DL * DL; ++ e)
+		Ci[e] = cinv[(int64_t)l * DL * DL + e];
+	double lv[DL];
+#pragma unroll
+	for(int q = 0; q < DL; ++ q)
+		lv[q] = rhs[lm_rbase[l] + q];
+	double Wl[DP];
+#pragma unroll
+	for(int r = 0; r < DP; ++ r)
+		Wl[r] = 0;
+	double *wo = W + a * DP * DL, *uo = Up + a * DP * DL;
+#pragma unroll
+	for(int q = 0; q < DL; ++ q)
+#pragma unroll
+		for(int r = 0; r < DP; ++ r) {
+			double s = 0;
+#pragma unroll
+			for(int t = 0; t < DL; ++ t)
+				s += U[r + DP * t] * Ci[t + DL * q];
+			wo[r + DP * q] = s;
+			uo[r + DP * q] = U[r + DP * q];
+			Wl[r] += s * lv[q];
+		}
+#pragma unroll
+	for(int r = 0; r < DP; ++ r)
+		xw[a * DP + r] = Wl[r];
+}
+
+// ---- S block accumulation: one wave per work item, lane = output element --------------------------
+template <int DP, int DL>
+__global__ __launch_bounds__(256)
+void s_accum_kernel(int64_t n_items, const int32_t *__restrict__ item_blk, const int32_t *__restrict__ item_beg,
+	const int32_t *__restrict__ item_slot, const int32_t *__restrict__ sblk_i1, const int32_t *__restrict__ sblk_i2,
+	const int64_t *__restrict__ sblk_aoff, const int32_t *__restrict__ pair_a, const int32_t *__restrict__ pair_b,
+	const double *__restrict__ W, const double *__restrict__ Up, const double *__restrict__ vals,
+	int add_A, double *__restrict__ S, int64_t ld, double *__restrict__ partial)
+{
+	const int64_t item = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	const int lane = threadIdx.x & 63;
+	if(item >= n_items || lane >= DP * DP)
+		return;
+	const int r = lane % DP, c = lane / DP;
+	const int32_t beg = item_beg[item], end = item_beg[item + 1];
+	double acc0 = 0, acc1 = 0;
+	int32_t q = beg;
+	for(; q + 1 < end; q += 2) { // two independent chains of loads in flight; summed in list order below
+		const double *w0 = W + (int64_t)pair_a[q] * DP * DL + r, *u0 = Up + (int64_t)pair_b[q] * DP * DL + c;
+		const double *w1 = W + (int64_t)pair_a[q + 1] * DP * DL + r, *u1 = Up + (int64_t)pair_b[q + 1] * DP * DL + c;
+		double s0 = 0, s1 = 0;
+#pragma unroll
+		for(int t = 0; t < DL; ++ t) {
+			s0 += w0[DP * t] * u0[DP * t];
+			s1 += w1[DP * t] * u1[DP * t];
+		}
+		acc0 = (acc0 + s0) + s1; // left-to-right, the order of the pair list
+	}
+	if(q < end) {
+		const double *w0 = W + (int64_t)pair_a[q] * DP * DL + r, *u0 = Up + (int64_t)pair_b[q] * DP * DL + c;
+		double s0 = 0;
+#pragma unroll
+		for(int t = 0; t < DL; ++ t)
+			s0 += w0[DP * t] * u0[DP * t];
+		acc0 += s0;
+	}
+	(void)acc1;
+	const int32_t b = item_blk[item];
+	const int32_t slot = item_slot[item];
+	if(slot >= 0) {
+		partial[(int64_t)slot * DP * DP + lane] = acc0;
+		return;
+	}
+	const int64_t aoff = sblk_aoff[b];
+	if(add_A && aoff >= 0)
+		acc0 = vals[aoff + lane] + acc0; // AddTo_FBS: S = A + W V
+	S[((int64_t)sblk_i1[b] * DP + r) + ((int64_t)sblk_i2[b] * DP + c) * ld] = acc0;
+}
+
+// blocks whose pair list was split: sum the partial slots in order (+ A)
+template <int DP>
+__global__ __launch_bounds__(256)
+void s_multi_kernel(int64_t n_multi, const int32_t *__restrict__ multi_blk, const int32_t *__restrict__ multi_ptr,
+	const int32_t *__restrict__ sblk_i1, const int32_t *__restrict__ sblk_i2, const int64_t *__restrict__ sblk_aoff,
+	const double *__restrict__ partial, const double *__restrict__ vals, int add_A, double *__restrict__ S, int64_t ld)
+{
+	const int64_t m = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	const int lane = threadIdx.x & 63;
+	if(m >= n_multi || lane >= DP * DP)
+		return;
+	const int32_t b = multi_blk[m];
+	double acc = 0;
+	for(int32_t s = multi_ptr[m]; s < multi_ptr[m + 1]; ++ s)
+		acc += partial[(int64_t)s * DP * DP + lane];
+	const int64_t aoff = sblk_aoff[b];
+	if(add_A && aoff >= 0)
+		acc = vals[aoff + lane] + acc;
+	const int r = lane % DP, c = lane / DP;
+	S[((int64_t)sblk_i1[b] * DP + r) + ((int64_t)sblk_i2[b] * DP + c) * ld] = acc;
+}
+
+// ---- reduced right-hand side: one wave per pose; written into padding column n_red of S -----------
+template <int DP>
+__global__ __launch_bounds__(256)
+void rhs_kernel(int64_t nc, const int32_t *__restrict__ cam_ptr, const int32_t *__restrict__ cam_obs,
+	const int64_t *__restrict__ pose_rbase, const double *__restrict__ xw, const double *__restrict__ rhs,
+	int add_eta, double *__restrict__ xcol)
+{
+	const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	const int lane = threadIdx.x & 63;
+	if(i >= nc)
+		return;
+	double s[DP];
+#pragma unroll
+	for(int r = 0; r < DP; ++ r)
+		s[r] = 0;
+	for(int32_t q = cam_ptr[i] + lane; q < cam_ptr[i + 1]; q += 64) {
+		const double *x = xw + (int64_t)cam_obs[q] * DP;
+#pragma unroll
+		for(int r = 0; r < DP; ++ r)
+			s[r] += x[r];
+	}
+#pragma unroll
+	for(int r = 0; r < DP; ++ r) {
+#pragma unroll
+		for(int off = 32; off > 0; off >>= 1)
+			s[r] += __shfl_xor(s[r], off);
+	}
+	if(lane < DP) {
+		double v = 0;
+#pragma unroll
+		for(int r = 0; r < DP; ++ r)
+			if(lane == r)
+				v = s[r];
+		if(add_eta)
+			v += rhs[pose_rbase[i] + lane];
+		xcol[i * DP + lane] = v;
+	}
+}
+
+// ---- back-substitution: one thread per landmark ------------------------------------------------
+template <int DP, int DL>
+__global__ __launch_bounds__(256)
+void backsubst_kernel(int64_t nl, const int32_t *__restrict__ lm_ptr, const int32_t *__restrict__ obs_pose,
+	const int64_t *__restrict__ lm_rbase, const double *__restrict__ Up, const double *__restrict__ cinv,
+	const double *__restrict__ dx, double *__restrict__ rhs)
+{
+	const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if(l >= nl)
+		return;
+	double t[DL];
+	const int64_t rb = lm_rbase[l];
+#pragma unroll
+	for(int q = 0; q < DL; ++ q)
+		t[q] = -rhs[rb + q]; // v_l = -v_l, LinearSolver_Schur.h:1867
+	for(int32_t a = lm_ptr[l]; a < lm_ptr[l + 1]; ++ a) {
+		const double *u = Up + (int64_t)a * DP * DL;
+		const double *d = dx + (int64_t)obs_pose[a] * DP;
+		double dv[DP];
+#pragma unroll
+		for(int r = 0; r < DP; ++ r)
+			dv[r] = d[r];
+#pragma unroll
+		for(int q = 0; q < DL; ++ q) {
+			double s = 0;
+#pragma unroll
+			for(int r = 0; r < DP; ++ r)
+				s += dv[r] * u[r + DP * q];
+			t[q] += s;
+		}
+	}
+	const double *Ci = cinv + l * DL * DL;
+#pragma unroll
+	for(int q = 0; q < DL; ++ q) {
+		double s = 0;
+#pragma unroll
+		for(int u = 0; u < DL; ++ u)
+			s += Ci[q + DL * u] * t[u];
+		rhs[rb + q] = s;
+	}
+}
+
+template <int DP>
+__global__ __launch_bounds__(256)
+void scatter_dx_kernel(int64_t nc, const int64_t *__restrict__ pose_rbase, const double *__restrict__ dx,
+	double *__restrict__ rhs)
+{
+	const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if(e >= nc * DP)
+		return;
+	rhs[pose_rbase[e / DP] + e % DP] = dx[e];
+}
+
+// --------------------------------------------------------------------------------------------------
+template <int DP, int DL>
+static void schur_form_t(spp_ctx *ctx, const double *d_vals, const double *d_rhs, double *S)
+{
+	SchurPlan &sp = ctx->schur;
+	hipStream_t s = ctx->stream;
+	const int64_t ld = sp.ld;
+	phase_begin(ctx, SPP_PHASE_SCHUR_INV);
+	SPP_HIP_CHECK(hipMemsetAsync(S, 0, (size_t)ld * ld * sizeof(double), s));
+	if(sp.nl)
+		hipLaunchKernelGGL((cinv_kernel<DL>), dim3((unsigned)((sp.nl + 255) / 256)), dim3(256), 0, s,
+			sp.nl, sp.lm_coff.p, d_vals, sp.cinv.p);
+	if(sp.no)
+		hipLaunchKernelGGL((obs_kernel<DP, DL>), dim3((unsigned)((sp.no + 255) / 256)), dim3(256), 0, s,
+			sp.no, sp.obs_lm.p, sp.obs_off.p, sp.lm_rbase.p, d_vals, d_rhs, sp.cinv.p, sp.W.p, sp.Up.p, sp.xw.p);
+	phase_end(ctx, SPP_PHASE_SCHUR_INV);
+	phase_begin(ctx, SPP_PHASE_SCHUR_GEMM);
+	if(sp.n_items)
+		hipLaunchKernelGGL((s_accum_kernel<DP, DL>), dim3((unsigned)((sp.n_items + 3) / 4)), dim3(256), 0, s,
+			sp.n_items, sp.item_blk.p, sp.item_beg.p, sp.item_slot.p, sp.sblk_i1.p, sp.sblk_i2.p, sp.sblk_aoff.p,
+			sp.pair_a.p, sp.pair_b.p, sp.W.p, sp.Up.p, d_vals, sp.add_A ? 1 : 0, S, ld, sp.partial.p);
+	if(sp.n_multi)
+		hipLaunchKernelGGL((s_multi_kernel<DP>), dim3((unsigned)((sp.n_multi + 3) / 4)), dim3(256), 0, s,
+			sp.n_multi, sp.multi_blk.p, sp.multi_ptr.p, sp.sblk_i1.p, sp.sblk_i2.p, sp.sblk_aoff.p,
+			sp.partial.p, d_vals, sp.add_A ? 1 : 0, S, ld);
+	phase_end(ctx, SPP_PHASE_SCHUR_GEMM);
+	phase_begin(ctx, SPP_PHASE_SCHUR_RHS);
+	if(sp.nc)
+		hipLaunchKernelGGL((rhs_kernel<DP>), dim3((unsigned)((sp.nc + 3) / 4)), dim3(256), 0, s,
+			sp.nc, sp.cam_ptr.p, sp.cam_obs.p, sp.pose_rbase.p, sp.xw.p, d_rhs, sp.add_A ? 1 : 0,
+			S + sp.n_red * ld);
+	phase_end(ctx, SPP_PHASE_SCHUR_RHS);
+	SPP_HIP_CHECK(hipGetLastError());
+}
+
+template <int DP, int DL>
+static int schur_finish_t(spp_ctx *ctx, const double *d_vals, double *S, double *d_rhs)
+{
+	(void)d_vals;
+	SchurPlan &sp = ctx->schur;
+	hipStream_t s = ctx->stream;
+	const int64_t ld = sp.ld;
+	phase_begin(ctx, SPP_PHASE_FACTOR);
+	dense_set_padding(ctx, S, ld, sp.n_red);
+	int ret = dense_potrf_upper(ctx, S, sp.n_red, ld, true);
+	phase_end(ctx, SPP_PHASE_FACTOR);
+	if(ret != SPP_OK)
+		return ret;
+	double *xcol = S + sp.n_red * ld;
+	phase_begin(ctx, SPP_PHASE_TRISOLVE);
+	dense_potrs_upper(ctx, S, sp.n_red, ld, xcol);
+	phase_end(ctx, SPP_PHASE_TRISOLVE);
+	phase_begin(ctx, SPP_PHASE_BACKSUBST);
+	if(sp.nl)
+		hipLaunchKernelGGL((backsubst_kernel<DP, DL>), dim3((unsigned)((sp.nl + 255) / 256)), dim3(256), 0, s,
+			sp.nl, sp.lm_ptr.p, sp.obs_pose.p, sp.lm_rbase.p, sp.Up.p, sp.cinv.p, xcol, d_rhs);
+	if(sp.nc)
+		hipLaunchKernelGGL((scatter_dx_kernel<DP>), dim3((unsigned)((sp.nc * DP + 255) / 256)), dim3(256), 0, s,
+			sp.nc, sp.pose_rbase.p, xcol, d_rhs);
+	phase_end(ctx, SPP_PHASE_BACKSUBST);
+	SPP_HIP_CHECK(hipGetLastError());
+	return SPP_OK;
+}
+
+void schur_form(spp_ctx *ctx, const double *d_vals, const double *d_rhs, double *d_S_rhs)
+{
+	if(ctx->schur.dp == 6)
+		schur_form_t<6, 3>(ctx, d_vals, d_rhs, d_S_rhs);
+	else
+		schur_form_t<3, 2>(ctx, d_vals, d_rhs, d_S_rhs);
+}
+
+int schur_finish(spp_ctx *ctx, const double *d_vals, double *d_S_rhs, double *d_rhs)
+{
+	if(ctx->schur.dp == 6)
+		return schur_finish_t<6, 3>(ctx, d_vals, d_S_rhs, d_rhs);
+	return schur_finish_t<3, 2>(ctx, d_vals, d_S_rhs, d_rhs);
+}
+
+} // namespace spp

@@ -1,0 +1,447 @@
+// spp_symbolic.cpp -- host-side symbolic analysis (integer work, once per block structure).
+//
+//  * schur_applicable / build_schur_plan: the guided Schur ordering and everything the reference
+//    recomputes structurally in every CLinearSolver_Schur::Solve_PosDef_Blocky call
+//      n_Calculate_GuidedOrdering      include/slam/LinearSolver_Schur.h:2154-2207, src/slam/LinearSolver_Schur.cpp:771-838
+//      Permute_UpperTriangular_To      src/slam/BlockMatrix.cpp:8183 (replaced by index indirection: no data moves)
+//      SliceTo x3 + TransposeTo        include/slam/LinearSolver_Schur.h:1699-1709 (replaced by the obs / pair lists)
+//      symbolic part of MultiplyToWith src/slam/BlockMatrixFBS.inl:1147-1304 (the S block pattern + pair lists)
+//  * min_degree_order: fill-reducing ordering of the block graph (the role of
+//    CMatrixOrdering::p_BlockOrdering, src/slam/OrderingMagic.cpp:701-1034, which calls amd_l2).
+//    This is our own quotient-graph approximate-minimum-degree implementation written from the
+//    published algorithm (Amestoy, Davis, Duff 1996); it is NOT the reference's AMD code and gives a
+//    different (equally valid) elimination order. Delta-x parity does not depend on the order.
+
+#include "spp_internal.h"
+#include <algorithm>
+#include <numeric>
+#include <string.h>
+
+namespace spp {
+
+void SchurPlan::release_all()
+{
+	lm_ptr.release(); lm_coff.release(); lm_rbase.release(); obs_pose.release(); obs_lm.release();
+	obs_off.release(); pose_rbase.release(); cam_ptr.release(); cam_obs.release(); item_blk.release();
+	item_beg.release(); item_slot.release(); sblk_i1.release(); sblk_i2.release(); sblk_aoff.release();
+	pair_a.release(); pair_b.release(); multi_blk.release(); multi_ptr.release(); cinv.release();
+	W.release(); Up.release(); xw.release(); partial.release(); S.release();
+	pose_block.clear(); lm_block.clear();
+}
+
+// Guided ordering is possible when there are exactly two block widths and the blocks of the
+// smaller width (landmarks) are not connected to each other (C block diagonal). Mirrors
+// LinearSolver_Schur.h:1586-1594 (fall back when there are not two vertex dimensions) and
+// :1721-1726 (the fast path requires b_BlockDiagonal()).
+bool schur_applicable(const Structure &st, int *dp_out, int *dl_out)
+{
+	int d_a = -1, d_b = -1;
+	for(int64_t j = 0; j < st.nb; ++ j) {
+		int d = st.dim[j];
+		if(d_a < 0 || d == d_a) d_a = d;
+		else if(d_b < 0 || d == d_b) d_b = d;
+		else return false;
+	}
+	if(d_a < 0 || d_b < 0)
+		return false;
+	int dp = std::max(d_a, d_b), dl = std::min(d_a, d_b);
+	if(!((dp == 6 && dl == 3) || (dp == 3 && dl == 2)))
+		return false; // kernel instantiations (BA: SE3 pose + XYZ; 2D SLAM: SE2 pose + XY)
+	int64_t n_lm = 0;
+	for(int64_t j = 0; j < st.nb; ++ j) {
+		if(st.dim[j] == dl)
+			++ n_lm;
+		for(int64_t p = st.col_ptr[j]; p < st.col_ptr[j + 1]; ++ p) {
+			int64_t i = st.row_idx[p];
+			if(i != j && st.dim[i] == dl && st.dim[j] == dl)
+				return false; // landmark-landmark block: C not block diagonal
+		}
+	}
+	// LinearSolver_Schur.h:1586: guided cut must leave fewer poses than half of the vertices
+	if(n_lm == 0 || (st.nb - n_lm) >= (st.nb + 1) / 2 + 0 * n_lm)
+		if(n_lm == 0)
+			return false;
+	*dp_out = dp;
+	*dl_out = dl;
+	return true;
+}
+
+static const int PAIR_CHUNK = 2048; // pairs per work item of the S accumulation
+
+void build_schur_plan(spp_ctx *ctx)
+{
+	const Structure &st = ctx->st;
+	SchurPlan &sp = ctx->schur;
+	sp.release_all();
+	int dp, dl;
+	SPP_REQUIRE(schur_applicable(st, &dp, &dl), SPP_E_UNSUPPORTED,
+		"Schur mode needs exactly two block widths ({6,3} or {3,2}) and a block-diagonal landmark part");
+	sp.dp = dp;
+	sp.dl = dl;
+	hipStream_t s = ctx->stream;
+
+	// ---- guided ordering: stable partition by width (LinearSolver_Schur.cpp:771-838)
+	std::vector<int32_t> pose_of(st.nb, -1), lm_of(st.nb, -1);
+	int64_t nc = 0, nl_total = 0, nl = 0;
+	for(int64_t j = 0; j < st.nb; ++ j) {
+		if(st.dim[j] == dp) {
+			pose_of[j] = (int32_t)nc ++;
+			sp.pose_block.push_back(j);
+		} else {
+			// landmark sharding: round-robin over ranks keeps track lengths balanced
+			if(nl_total % ctx->shard_world == ctx->shard_rank) {
+				lm_of[j] = (int32_t)nl ++;
+				sp.lm_block.push_back(j);
+			}
+			++ nl_total;
+		}
+	}
+	sp.nc = nc;
+	sp.nl = nl;
+	sp.nl_total = nl_total;
+	sp.add_A = (ctx->shard_rank == 0);
+	sp.n_red = nc * dp;
+	sp.ld = ((sp.n_red + 1 + DENSE_NB - 1) / DENSE_NB) * DENSE_NB; // at least one padding column (rhs)
+	SPP_REQUIRE(sp.ld <= 65536, SPP_E_UNSUPPORTED, "reduced camera system too large for the dense path");
+
+	// ---- observations: every pose-landmark block, sorted by (landmark, pose)
+	struct Obs { int32_t lm, pose; int64_t off; };
+	std::vector<Obs> obs;
+	std::vector<int64_t> lm_coff(nl, -1);
+	struct ABlk { int32_t i1, i2; int64_t off; };
+	std::vector<ABlk> ablk;
+	for(int64_t j = 0; j < st.nb; ++ j) {
+		for(int64_t p = st.col_ptr[j]; p < st.col_ptr[j + 1]; ++ p) {
+			const int64_t i = st.row_idx[p]; // i <= j
+			const bool pi = st.dim[i] == dp, pj = st.dim[j] == dp;
+			if(pi && pj)
+				ablk.push_back({pose_of[i], pose_of[j], st.blk_off[p]}); // i <= j and stable partition keep i1 <= i2
+			else if(!pi && !pj) {
+				if(lm_of[j] >= 0)
+					lm_coff[lm_of[j]] = st.blk_off[p]; // diagonal C block
+			} else if(pi) { // block (pose i, landmark j): dp x dl as stored
+				if(lm_of[j] >= 0)
+					obs.push_back({lm_of[j], pose_of[i], st.blk_off[p] << 1});
+			} else {       // block (landmark i, pose j): stored transposed, dl x dp
+				if(lm_of[i] >= 0)
+					obs.push_back({lm_of[i], pose_of[j], (st.blk_off[p] << 1) | 1});
+			}
+		}
+	}
+	for(int64_t l = 0; l < nl; ++ l)
+		SPP_REQUIRE(lm_coff[l] >= 0, SPP_E_BADARG, "landmark without a diagonal block");
+	std::sort(obs.begin(), obs.end(), [](const Obs &a, const Obs &b) {
+		return a.lm != b.lm ? a.lm < b.lm : a.pose < b.pose; });
+	const int64_t no = (int64_t)obs.size();
+	SPP_REQUIRE(no < (int64_t(1) << 31), SPP_E_UNSUPPORTED, "too many observations for 32-bit obs indices");
+	sp.no = no;
+	std::vector<int32_t> lm_ptr(nl + 1, 0), obs_pose(no), obs_lm(no);
+	std::vector<int64_t> obs_off(no);
+	for(int64_t a = 0; a < no; ++ a) {
+		++ lm_ptr[obs[a].lm + 1];
+		obs_pose[a] = obs[a].pose;
+		obs_lm[a] = obs[a].lm;
+		obs_off[a] = obs[a].off;
+	}
+	for(int64_t l = 0; l < nl; ++ l)
+		lm_ptr[l + 1] += lm_ptr[l];
+
+	// ---- per-pose observation lists (ascending landmark = ascending obs index)
+	std::vector<int32_t> cam_ptr(nc + 1, 0), cam_obs(no);
+	for(int64_t a = 0; a < no; ++ a)
+		++ cam_ptr[obs_pose[a] + 1];
+	for(int64_t c = 0; c < nc; ++ c)
+		cam_ptr[c + 1] += cam_ptr[c];
+	{
+		std::vector<int32_t> fill(cam_ptr.begin(), cam_ptr.end() - 1);
+		for(int64_t a = 0; a < no; ++ a)
+			cam_obs[fill[obs_pose[a]] ++] = (int32_t)a;
+	}
+
+	// ---- S block pattern and pair lists. Key = (i1 <= i2). Two stable counting passes
+	// (by i1, then by i2... ) would reorder landmarks; instead count per key with a dense or
+	// hashed index and fill in landmark order, which keeps the reference's accumulation order
+	// (MultiplyToWith_FBS walks the columns of V = landmarks in ascending order).
+	int64_t n_pairs = 0;
+	for(int64_t l = 0; l < nl; ++ l) {
+		int64_t k = lm_ptr[l + 1] - lm_ptr[l];
+		n_pairs += k * (k + 1) / 2;
+	}
+	SPP_REQUIRE(n_pairs < (int64_t(1) << 31), SPP_E_UNSUPPORTED, "too many block products for 32-bit pair indices");
+	sp.n_pairs = n_pairs;
+	// sort-free grouping: first pass counts pairs per row i1 (bucket), second pass sorts each
+	// bucket's keys by i2 with a counting sort over nc. Memory: O(n_pairs).
+	std::vector<int32_t> pair_a(n_pairs), pair_b(n_pairs);
+	std::vector<int32_t> sblk_i1, sblk_i2;
+	std::vector<int64_t> sblk_aoff;
+	std::vector<int64_t> sblk_beg; // pair range per S block
+	{
+		// bucket by i1
+		std::vector<int64_t> row_cnt(nc + 1, 0);
+		for(int64_t l = 0; l < nl; ++ l)
+			for(int32_t a = lm_ptr[l]; a < lm_ptr[l + 1]; ++ a)
+				row_cnt[obs_pose[a] + 1] += lm_ptr[l + 1] - a; // pairs (a, b >= a)
+		for(int64_t c = 0; c < nc; ++ c)
+			row_cnt[c + 1] += row_cnt[c];
+		std::vector<int32_t> tmp_a(n_pairs), tmp_b(n_pairs);
+		{
+			std::vector<int64_t> fill(row_cnt.begin(), row_cnt.end() - 1);
+			for(int64_t l = 0; l < nl; ++ l)
+				for(int32_t a = lm_ptr[l]; a < lm_ptr[l + 1]; ++ a) {
+					int64_t &f = fill[obs_pose[a]];
+					for(int32_t b = a; b < lm_ptr[l + 1]; ++ b) {
+						tmp_a[f] = a;
+						tmp_b[f] = b;
+						++ f;
+					}
+				}
+		}
+		// A blocks grouped by row for merging
+		std::vector<std::vector<std::pair<int32_t, int64_t> > > a_by_row(nc);
+		for(size_t q = 0; q < ablk.size(); ++ q)
+			a_by_row[ablk[q].i1].push_back(std::make_pair(ablk[q].i2, ablk[q].off));
+		std::vector<int64_t> col_cnt(nc + 1);
+		std::vector<int64_t> a_of_col(nc);
+		int64_t out = 0;
+		for(int64_t i1 = 0; i1 < nc; ++ i1) {
+			const int64_t b0 = row_cnt[i1], b1 = row_cnt[i1 + 1];
+			std::fill(col_cnt.begin(), col_cnt.end(), 0);
+			std::fill(a_of_col.begin() + i1, a_of_col.end(), -1);
+			for(int64_t q = b0; q < b1; ++ q)
+				++ col_cnt[obs_pose[tmp_b[q]] + 1];
+			for(size_t q = 0; q < a_by_row[i1].size(); ++ q)
+				a_of_col[a_by_row[i1][q].first] = a_by_row[i1][q].second;
+			// blocks of this row, ascending i2
+			std::vector<int64_t> start(nc + 1, 0);
+			for(int64_t c = i1; c < nc; ++ c) {
+				start[c] = out;
+				if(col_cnt[c + 1] || a_of_col[c] >= 0) {
+					sblk_i1.push_back((int32_t)i1);
+					sblk_i2.push_back((int32_t)c);
+					sblk_aoff.push_back(a_of_col[c]);
+					sblk_beg.push_back(out);
+				}
+				out += col_cnt[c + 1];
+			}
+			for(int64_t q = b0; q < b1; ++ q) { // stable: landmark order preserved
+				int64_t &f = start[obs_pose[tmp_b[q]]];
+				pair_a[f] = tmp_a[q];
+				pair_b[f] = tmp_b[q];
+				++ f;
+			}
+		}
+		sblk_beg.push_back(out);
+	}
+	const int64_t n_sblk = (int64_t)sblk_i1.size();
+	sp.n_sblk = n_sblk;
+
+	// ---- work items: chunks of at most PAIR_CHUNK pairs
+	std::vector<int32_t> item_blk, item_beg, item_slot, multi_blk, multi_ptr;
+	int32_t n_slots = 0;
+	for(int64_t b = 0; b < n_sblk; ++ b) {
+		const int64_t beg = sblk_beg[b], end = sblk_beg[b + 1];
+		const int64_t nchunk = std::max<int64_t>(1, (end - beg + PAIR_CHUNK - 1) / PAIR_CHUNK);
+		if(nchunk > 1) {
+			multi_blk.push_back((int32_t)b);
+			multi_ptr.push_back(n_slots);
+		}
+		for(int64_t c = 0; c < nchunk; ++ c) {
+			item_blk.push_back((int32_t)b);
+			item_beg.push_back((int32_t)(beg + c * PAIR_CHUNK));
+			item_slot.push_back(nchunk > 1 ? n_slots ++ : -1);
+		}
+	}
+	multi_ptr.push_back(n_slots);
+	item_beg.push_back((int32_t)n_pairs);
+	// the end of item i is min(item_beg[i+1], end of its block) == item_beg[i+1] by construction
+	sp.n_items = (int64_t)item_blk.size();
+	sp.n_multi = (int64_t)multi_blk.size();
+
+	// ---- rhs offsets
+	std::vector<int64_t> pose_rbase(nc), lm_rbase(nl);
+	for(int64_t c = 0; c < nc; ++ c)
+		pose_rbase[c] = st.base[sp.pose_block[c]];
+	for(int64_t l = 0; l < nl; ++ l)
+		lm_rbase[l] = st.base[sp.lm_block[l]];
+
+	// ---- upload
+	sp.lm_ptr.upload(lm_ptr, s);
+	sp.lm_coff.upload(lm_coff, s);
+	sp.lm_rbase.upload(lm_rbase, s);
+	sp.obs_pose.upload(obs_pose, s);
+	sp.obs_lm.upload(obs_lm, s);
+	sp.obs_off.upload(obs_off, s);
+	sp.pose_rbase.upload(pose_rbase, s);
+	sp.cam_ptr.upload(cam_ptr, s);
+	sp.cam_obs.upload(cam_obs, s);
+	sp.item_blk.upload(item_blk, s);
+	sp.item_beg.upload(item_beg, s);
+	sp.item_slot.upload(item_slot, s);
+	sp.sblk_i1.upload(sblk_i1, s);
+	sp.sblk_i2.upload(sblk_i2, s);
+	sp.sblk_aoff.upload(sblk_aoff, s);
+	sp.pair_a.upload(pair_a, s);
+	sp.pair_b.upload(pair_b, s);
+	sp.multi_blk.upload(multi_blk, s);
+	sp.multi_ptr.upload(multi_ptr, s);
+	sp.cinv.reserve((size_t)std::max<int64_t>(1, nl) * dl * dl);
+	sp.W.reserve((size_t)std::max<int64_t>(1, no) * dp * dl);
+	sp.Up.reserve((size_t)std::max<int64_t>(1, no) * dp * dl);
+	sp.xw.reserve((size_t)std::max<int64_t>(1, no) * dp);
+	sp.partial.reserve((size_t)std::max<int32_t>(1, n_slots) * dp * dp);
+	SPP_HIP_CHECK(hipStreamSynchronize(s)); // host vectors die here
+
+	// ---- accounting (SURVEY 8d "Schur" + "Dense reduced solve")
+	const double n = (double)sp.n_red;
+	ctx->factor_flops = (int64_t)(n * n * n / 3.0 + 2.0 * n * n);
+	ctx->factor_nnz = sp.ld * sp.ld;
+	const int64_t blk_pl = 8 * dp * dl, blk_pp = 8 * dp * dp, blk_ll = 8 * dl * dl;
+	ctx->solve_bytes = blk_pl * no + blk_ll * nl + blk_pp * (int64_t)ablk.size() + 8 * st.n /* read */
+		+ blk_pp * n_sblk + 8 * st.n /* write S, solution */
+		+ 8 * sp.n_red * sp.n_red /* dense factor touched once in place */;
+}
+
+// --------------------------------------------------------------------------------------------------
+// Approximate minimum degree on the block graph (A + A^T pattern of the upper-triangular input).
+// Quotient graph with element absorption, approximate external degrees (|Le \ Lp| bound),
+// mass elimination of indistinguishable variables is omitted (block graphs here are small).
+// order[k] = block column eliminated k-th.
+// --------------------------------------------------------------------------------------------------
+void min_degree_order(int64_t nb, const int64_t *col_ptr, const int64_t *row_idx, std::vector<int64_t> &order)
+{
+	order.clear();
+	order.reserve(nb);
+	if(nb == 0)
+		return;
+	// adjacency (variables) of A + A^T without the diagonal
+	std::vector<std::vector<int32_t> > adj(nb), elems(nb); // variable -> variable nbrs / element nbrs
+	for(int64_t j = 0; j < nb; ++ j)
+		for(int64_t p = col_ptr[j]; p < col_ptr[j + 1]; ++ p) {
+			int64_t i = row_idx[p];
+			if(i != j) {
+				adj[i].push_back((int32_t)j);
+				adj[j].push_back((int32_t)i);
+			}
+		}
+	for(int64_t i = 0; i < nb; ++ i) {
+		std::sort(adj[i].begin(), adj[i].end());
+		adj[i].erase(std::unique(adj[i].begin(), adj[i].end()), adj[i].end());
+	}
+	std::vector<std::vector<int32_t> > elem_vars(nb); // element (named by its pivot) -> variables
+	std::vector<uint8_t> state(nb, 0);               // 0 variable, 1 element, 2 absorbed element
+	std::vector<int64_t> degree(nb);
+	std::vector<int64_t> w(nb, -1);                  // |Le \ Lp| workspace, stamped
+	std::vector<int64_t> mark(nb, -1);
+	// degree buckets (doubly linked lists)
+	std::vector<int32_t> head(nb + 1, -1), next(nb, -1), prev(nb, -1);
+	auto bucket_insert = [&](int32_t v) {
+		int64_t d = std::min<int64_t>(degree[v], nb);
+		next[v] = head[d];
+		prev[v] = -1;
+		if(head[d] >= 0) prev[head[d]] = v;
+		head[d] = v;
+	};
+	auto bucket_remove = [&](int32_t v) {
+		int64_t d = std::min<int64_t>(degree[v], nb);
+		if(prev[v] >= 0) next[prev[v]] = next[v]; else head[d] = next[v];
+		if(next[v] >= 0) prev[next[v]] = prev[v];
+	};
+	for(int64_t i = 0; i < nb; ++ i) {
+		degree[i] = (int64_t)adj[i].size();
+		bucket_insert((int32_t)i);
+	}
+	int64_t mindeg = 0;
+	std::vector<int32_t> Lp;
+	for(int64_t step = 0; step < nb; ++ step) {
+		while(mindeg <= nb && head[mindeg] < 0)
+			++ mindeg;
+		const int32_t p = head[mindeg];
+		bucket_remove(p);
+		order.push_back(p);
+		// Lp = adj(p) U (union of Le for e in elems(p)) \ {p}
+		Lp.clear();
+		mark[p] = step;
+		for(size_t q = 0; q < adj[p].size(); ++ q) {
+			int32_t v = adj[p][q];
+			if(state[v] == 0 && mark[v] != step) {
+				mark[v] = step;
+				Lp.push_back(v);
+			}
+		}
+		for(size_t q = 0; q < elems[p].size(); ++ q) {
+			int32_t e = elems[p][q];
+			if(state[e] != 1)
+				continue;
+			for(size_t t = 0; t < elem_vars[e].size(); ++ t) {
+				int32_t v = elem_vars[e][t];
+				if(state[v] == 0 && mark[v] != step) {
+					mark[v] = step;
+					Lp.push_back(v);
+				}
+			}
+			state[e] = 2; // absorbed into p
+			std::vector<int32_t>().swap(elem_vars[e]);
+		}
+		state[p] = 1;
+		std::vector<int32_t>().swap(adj[p]);
+		std::vector<int32_t>().swap(elems[p]);
+		elem_vars[p] = Lp;
+		const int64_t lp = (int64_t)Lp.size();
+		// w(e) = |Le \ Lp| for every element adjacent to a variable of Lp
+		for(size_t q = 0; q < Lp.size(); ++ q) {
+			int32_t v = Lp[q];
+			for(size_t t = 0; t < elems[v].size(); ++ t) {
+				int32_t e = elems[v][t];
+				if(state[e] != 1)
+					continue;
+				if(w[e] < step * (nb + 1)) { // first touch in this step: stamp + live size
+					int64_t sz = 0;
+					for(size_t u = 0; u < elem_vars[e].size(); ++ u)
+						if(state[elem_vars[e][u]] == 0)
+							++ sz;
+					w[e] = step * (nb + 1) + sz;
+				}
+				-- w[e];
+			}
+		}
+		for(size_t q = 0; q < Lp.size(); ++ q) {
+			const int32_t v = Lp[q];
+			bucket_remove(v);
+			// prune: variable neighbours inside Lp (now covered by element p) and dead entries
+			{
+				std::vector<int32_t> &a = adj[v];
+				size_t o = 0;
+				for(size_t t = 0; t < a.size(); ++ t)
+					if(state[a[t]] == 0 && mark[a[t]] != step)
+						a[o ++] = a[t];
+				a.resize(o);
+			}
+			int64_t d = (int64_t)adj[v].size() + (lp - 1);
+			{
+				std::vector<int32_t> &el = elems[v];
+				size_t o = 0;
+				for(size_t t = 0; t < el.size(); ++ t) {
+					int32_t e = el[t];
+					if(state[e] != 1)
+						continue;
+					int64_t we = w[e] - step * (nb + 1);
+					if(we <= 0) {
+						// Le is a subset of Lp: aggressive absorption
+						continue;
+					}
+					d += we;
+					el[o ++] = e;
+				}
+				el.resize(o);
+				el.push_back(p);
+			}
+			degree[v] = std::min<int64_t>(std::min<int64_t>(d, nb - step - 1), degree[v] + lp - 1);
+			if(degree[v] < 0) degree[v] = 0;
+			bucket_insert(v);
+			if(degree[v] < mindeg)
+				mindeg = degree[v];
+		}
+	}
+}
+
+} // namespace spp
