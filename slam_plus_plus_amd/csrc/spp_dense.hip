@@ -259,7 +259,7 @@ void potrf_diag_kernel(double *__restrict__ Ablk, int64_t ld, int n_valid, int h
 // Every workgroup recomputes x_k (128 x 128 GEMV out of L2); workgroup 0 stores it to `xout`
 // (a buffer distinct from y: the other workgroups still read y_k), workgroup b > 0 updates 256 rows.
 __global__ __launch_bounds__(256)
-void trsv_back_kernel(const double *__restrict__ R, int64_t ld, int64_t k0, const double *__restrict__ tinv,
+void trsv_back_kernel(const double *__restrict__ R, int64_t ld, int64_t k0, int nv, const double *__restrict__ tinv,
 	double *__restrict__ y, double *__restrict__ xout)
 {
 	__shared__ double xk[NB];
@@ -269,7 +269,7 @@ void trsv_back_kernel(const double *__restrict__ R, int64_t ld, int64_t k0, cons
 		const int r = tid & (NB - 1), h = tid >> 7;
 		double s = 0;
 		for(int c = h * 64; c < h * 64 + 64; ++ c)
-			s += tinv[r + c * NB] * y[k0 + c];
+			if(c < nv) s += tinv[r + c * NB] * y[k0 + c];
 		part[h][r] = s;
 	}
 	__syncthreads();
@@ -285,7 +285,7 @@ void trsv_back_kernel(const double *__restrict__ R, int64_t ld, int64_t k0, cons
 		const double *row = R + i + k0 * ld;
 		double s = 0;
 #pragma unroll 8
-		for(int c = 0; c < NB; ++ c)
+		for(int c = 0; c < nv; ++ c) // real columns only: the padding of the last block holds the rhs column
 			s += row[(int64_t)c * ld] * xk[c];
 		y[i] -= s;
 	}
@@ -377,7 +377,8 @@ void dense_potrs_upper(spp_ctx *ctx, const double *d_R, int64_t n, int64_t ld, d
 		const int64_t k0 = k * NB;
 		const double *tinv = ctx->dense.tinv_all.p + (size_t)k * NB * NB;
 		unsigned nwg = 1 + (unsigned)((k0 + 255) / 256);
-		hipLaunchKernelGGL(trsv_back_kernel, dim3(nwg), dim3(256), 0, s, d_R, ld, k0, tinv, d_b, ctx->dense.xtmp.p);
+		const int nv = (int)((n - k0 < NB) ? (n - k0) : NB);
+		hipLaunchKernelGGL(trsv_back_kernel, dim3(nwg), dim3(256), 0, s, d_R, ld, k0, nv, tinv, d_b, ctx->dense.xtmp.p);
 	}
 	SPP_HIP_CHECK(hipGetLastError());
 	SPP_HIP_CHECK(hipMemcpyAsync(d_b, ctx->dense.xtmp.p, n * sizeof(double), hipMemcpyDeviceToDevice, s));

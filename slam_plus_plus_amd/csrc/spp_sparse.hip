@@ -1,0 +1,710 @@
+// spp_sparse.hip -- supernodal multifrontal block Cholesky (R^T R = P Lambda P^T, R upper) and the two
+// triangular solves on gfx950, fp64: the sparse path for pose graphs (configs 1, 2) and the fallback
+// whenever guided Schur does not apply.
+//
+// Replaces CLinearSolver_UberBlock::Solve_PosDef_Blocky (reference include/slam/LinearSolver_UberBlock.h:312-426):
+//   p_BlockOrdering (AMD)                   src/slam/OrderingMagic.cpp:701       -> min_degree_order (ours, host)
+//   Permute_UpperTriangular_To              src/slam/BlockMatrix.cpp:8183        -> index lists, no data moved
+//   Build_EliminationTree / n_Build_EReach  src/slam/BlockMatrix.cpp:9403,9453   -> etree + postorder + supernodes (host, once)
+//   CholeskyOf_FBS (up-looking, serial)     src/slam/BlockMatrixFBS.inl:2342     -> multifrontal fronts, level-parallel
+//   UpperTriangularTranspose_Solve_FBS      src/slam/BlockMatrixFBS.inl:2136     -> fwd_kernel (leaves -> root)
+//   UpperTriangular_Solve_FBS               src/slam/BlockMatrixFBS.inl:2233     -> bwd_kernel (root -> leaves)
+//   (Inverse)Permute_LeftHandSide_Vector    src/slam/BlockMatrix.cpp:9323,9379   -> gather/scatter by scalar permutation
+//
+// The reference factors column by column with sorted-list merges (no supernodes, no BLAS3, serial:
+// SURVEY 8a-7). Here every supernode owns a dense frontal matrix F (h x h, upper part used, column
+// major) resident in HBM for the whole solve (288 GB: no stack juggling):
+//   F <- blocks of Lambda in the supernode's rows  (+) extend-add of the children's update matrices
+//   F11 = R11^T R11 ; R12 = R11^-T F12 ; F22 -= R12^T R12         (partial dense factorization)
+// All fronts of one level of the assembly tree are processed by ONE launch (a workgroup per front);
+// fronts too large for one workgroup go through the multi-workgroup dense kernels of spp_dense.hip
+// (MFMA trailing update). Children are summed into their parent in a fixed order and nothing uses
+// atomics, so the factor is bit-reproducible.
+//
+// Roofline: small fronts are latency/HBM bound (SURVEY 7.3 "latency, not bandwidth, for pose
+// graphs"); only the large fronts near the root reach the MFMA path.
+
+#include "spp_internal.h"
+#include <algorithm>
+#include <numeric>
+
+namespace spp {
+
+struct SparsePlan {
+	int64_t nb = 0, n = 0;
+	int64_t n_snodes = 0, n_levels = 0;
+	int64_t front_doubles = 0, vbuf_doubles = 0;
+	// host
+	std::vector<int32_t> h_level_ptr;          // [n_levels+1]
+	std::vector<int32_t> h_front_h, h_front_w; // per supernode (scalar sizes)
+	std::vector<int64_t> h_front_off;
+	std::vector<int32_t> h_level_fronts;
+	std::vector<int32_t> h_big;                // supernodes routed through the dense kernels
+	// device
+	DevBuf<int32_t> level_fronts;              // fronts grouped by level
+	DevBuf<int64_t> front_off;                 // [ns] offset of F in `fronts`
+	DevBuf<int32_t> front_h, front_w, front_ld; // [ns]
+	DevBuf<int64_t> front_voff;                // [ns] offset of the solve work vector
+	DevBuf<int32_t> asm_ptr;                   // [ns+1]
+	DevBuf<int64_t> asm_src;                   // [n_asm] (offset in vals << 1) | transpose
+	DevBuf<int32_t> asm_dst;                   // [n_asm] local scalar row | local scalar col << 16
+	DevBuf<int32_t> asm_shape;                 // [n_asm] dst rows | dst cols << 8
+	DevBuf<int32_t> child_ptr;                 // [ns+1]
+	DevBuf<int32_t> child_list;                // children in fixed (ascending) order
+	DevBuf<int32_t> rel_ptr;                   // [ns+1] into rel (per supernode as a CHILD)
+	DevBuf<int32_t> rel;                       // parent-local scalar index of each update row of the child
+	DevBuf<int32_t> rows_ptr;                  // [ns+1]
+	DevBuf<int32_t> rows;                      // permuted global scalar index of each local row
+	DevBuf<int32_t> perm_scalar;               // [n] permuted scalar -> original scalar
+	DevBuf<double> fronts, vbuf, xperm;
+	DevBuf<int> info;
+};
+
+// --------------------------------------------------------------------------------------------------
+// host symbolic
+// --------------------------------------------------------------------------------------------------
+namespace {
+
+struct Sym {
+	int64_t nb;
+	std::vector<int64_t> order, inv;            // final elimination order and its inverse
+	std::vector<std::vector<int32_t> > up;      // permuted upper pattern: rows (< col) of each column
+	std::vector<int32_t> parent;
+};
+
+static void etree_of(int64_t nb, const std::vector<std::vector<int32_t> > &up, std::vector<int32_t> &parent)
+{
+	std::vector<int32_t> anc(nb, -1);
+	parent.assign(nb, -1);
+	for(int64_t j = 0; j < nb; ++ j)
+		for(size_t q = 0; q < up[j].size(); ++ q) {
+			int32_t i = up[j][q];
+			while(i != -1 && i < j) {
+				int32_t next = anc[i];
+				anc[i] = (int32_t)j;
+				if(next == -1)
+					parent[i] = (int32_t)j;
+				i = next;
+			}
+		}
+}
+
+static void permuted_pattern(const Structure &st, const std::vector<int64_t> &inv, std::vector<std::vector<int32_t> > &up)
+{
+	up.assign(st.nb, std::vector<int32_t>());
+	for(int64_t j = 0; j < st.nb; ++ j)
+		for(int64_t p = st.col_ptr[j]; p < st.col_ptr[j + 1]; ++ p) {
+			int64_t i = st.row_idx[p];
+			if(i == j)
+				continue;
+			int64_t a = inv[i], b = inv[j];
+			if(a > b) std::swap(a, b);
+			up[b].push_back((int32_t)a);
+		}
+	for(int64_t j = 0; j < st.nb; ++ j)
+		std::sort(up[j].begin(), up[j].end());
+}
+
+static void postorder(const std::vector<int32_t> &parent, std::vector<int32_t> &post)
+{
+	const int64_t nb = (int64_t)parent.size();
+	std::vector<int32_t> head(nb, -1), next(nb, -1);
+	for(int64_t j = nb; j > 0;) { // children lists in ascending order
+		-- j;
+		if(parent[j] >= 0) {
+			next[j] = head[parent[j]];
+			head[parent[j]] = (int32_t)j;
+		}
+	}
+	post.clear();
+	post.reserve(nb);
+	std::vector<int32_t> stack;
+	for(int64_t r = 0; r < nb; ++ r) {
+		if(parent[r] >= 0)
+			continue;
+		stack.push_back((int32_t)r);
+		while(!stack.empty()) {
+			int32_t v = stack.back();
+			int32_t c = head[v];
+			if(c >= 0) {
+				head[v] = next[c];
+				stack.push_back(c);
+			} else {
+				stack.pop_back();
+				post.push_back(v);
+			}
+		}
+	}
+}
+
+} // namespace
+
+void sparse_release(spp_ctx *ctx)
+{
+	delete ctx->sparse;
+	ctx->sparse = nullptr;
+}
+
+int64_t sparse_info(const spp_ctx *ctx, int what)
+{
+	if(!ctx->sparse)
+		return 0;
+	if(what == SPP_INFO_N_SUPERNODES) return ctx->sparse->n_snodes;
+	if(what == SPP_INFO_N_LEVELS) return ctx->sparse->n_levels;
+	return 0;
+}
+
+static const int BIG_FRONT_H = 1 << 30; // threshold (scalar height) above which a front uses the dense kernels
+
+void sparse_analyze(spp_ctx *ctx)
+{
+	const Structure &st = ctx->st;
+	const int64_t nb = st.nb;
+	sparse_release(ctx);
+	SparsePlan *sp = new SparsePlan;
+	ctx->sparse = sp;
+	sp->nb = nb;
+	sp->n = st.n;
+	SPP_REQUIRE(st.n < (int64_t(1) << 31), SPP_E_UNSUPPORTED, "sparse path: scalar dimension exceeds 32-bit indices");
+
+	// ---- 1. fill-reducing order, then postorder of its elimination tree
+	std::vector<int64_t> order0;
+	min_degree_order(nb, st.col_ptr.data(), st.row_idx.data(), order0);
+	std::vector<int64_t> inv(nb);
+	for(int64_t k = 0; k < nb; ++ k)
+		inv[order0[k]] = k;
+	std::vector<std::vector<int32_t> > up;
+	std::vector<int32_t> parent, post;
+	permuted_pattern(st, inv, up);
+	etree_of(nb, up, parent);
+	postorder(parent, post);
+	std::vector<int64_t> order(nb);
+	for(int64_t k = 0; k < nb; ++ k)
+		order[k] = order0[post[k]];
+	for(int64_t k = 0; k < nb; ++ k)
+		inv[order[k]] = k;
+	permuted_pattern(st, inv, up);
+	etree_of(nb, up, parent);
+	ctx->order = order;
+
+	// ---- 2. row structure of every row of R (= column structure of L), children merged upward
+	// struct[j] = sorted block columns c > j with R(j, c) != 0
+	std::vector<std::vector<int32_t> > rstruct(nb);
+	{
+		// entries of A in row j right of the diagonal: from the permuted upper pattern, (a, b) a < b
+		for(int64_t b = 0; b < nb; ++ b)
+			for(size_t q = 0; q < up[b].size(); ++ q)
+				rstruct[up[b][q]].push_back((int32_t)b);
+		std::vector<int32_t> tmp;
+		for(int64_t j = 0; j < nb; ++ j) {
+			std::vector<int32_t> &s = rstruct[j];
+			std::sort(s.begin(), s.end());
+			s.erase(std::unique(s.begin(), s.end()), s.end());
+			// push to the parent: struct[parent] U= struct[j] \ {parent}
+			const int32_t p = parent[j];
+			SPP_REQUIRE(p < 0 || (!s.empty() && s[0] == p), SPP_E_HIP, "internal: etree/structure mismatch");
+			if(p >= 0) {
+				tmp.clear();
+				std::vector<int32_t> &ps = rstruct[p];
+				// ps is not sorted yet (raw A entries): append, it is sorted/uniqued when p is visited
+				ps.insert(ps.end(), s.begin() + 1, s.end());
+			}
+		}
+	}
+
+	// ---- 3. fundamental supernodes + relaxed amalgamation of the last child
+	std::vector<int32_t> n_child(nb, 0);
+	for(int64_t j = 0; j < nb; ++ j)
+		if(parent[j] >= 0)
+			++ n_child[parent[j]];
+	std::vector<int32_t> sn_first; // first block column of each supernode
+	std::vector<int32_t> sn_of(nb);
+	for(int64_t j = 0; j < nb; ++ j) {
+		bool join = j > 0 && parent[j - 1] == j && n_child[j] == 1 &&
+			rstruct[j - 1].size() == rstruct[j].size() + 1;
+		if(!join)
+			sn_first.push_back((int32_t)j);
+		sn_of[j] = (int32_t)sn_first.size() - 1;
+	}
+	// relaxed amalgamation: merge supernode s into the supernode that starts right after it when
+	// that one is its parent and the explicit zeros stay small
+	{
+		std::vector<int64_t> base = st.base; // unused here, dims through order
+		std::vector<int32_t> pdim(nb);
+		for(int64_t k = 0; k < nb; ++ k)
+			pdim[k] = st.dim[order[k]];
+		std::vector<int32_t> first2;
+		int64_t ns = (int64_t)sn_first.size();
+		std::vector<int32_t> sn_last(ns);
+		for(int64_t s = 0; s < ns; ++ s)
+			sn_last[s] = (s + 1 < ns ? sn_first[s + 1] : (int32_t)nb) - 1;
+		// scalar width / height helpers on current (possibly merged) supernodes
+		std::vector<char> merged_into_next(ns, 0);
+		// process from the leaves: greedy chain merging
+		std::vector<int64_t> cur_w(ns), cur_hbeyond(ns);
+		for(int64_t s = 0; s < ns; ++ s) {
+			int64_t w = 0;
+			for(int32_t c = sn_first[s]; c <= sn_last[s]; ++ c)
+				w += pdim[c];
+			int64_t hb = 0;
+			const std::vector<int32_t> &rs = rstruct[sn_last[s]];
+			for(size_t q = 0; q < rs.size(); ++ q)
+				hb += pdim[rs[q]];
+			cur_w[s] = w;
+			cur_hbeyond[s] = hb;
+		}
+		for(int64_t s = 0; s + 1 < ns; ++ s) {
+			const int32_t last = sn_last[s];
+			if(parent[last] != last + 1)
+				continue; // the next supernode is not the parent
+			const int64_t wp = cur_w[s + 1], hp = wp + cur_hbeyond[s + 1];
+			const int64_t ws = cur_w[s], hs_beyond = cur_hbeyond[s];
+			// rows of s beyond its pivot block are a subset of the parent's rows (incl. its pivot block)
+			const int64_t zeros = ws * (hp - hs_beyond);
+			const int64_t merged_panel = (ws + wp) * (ws + hp);
+			const bool small = (ws + wp) <= 24;
+			if(zeros == 0 || small || (double)zeros <= 0.12 * (double)merged_panel) {
+				merged_into_next[s] = 1;
+				cur_w[s + 1] = ws + wp; // the merged supernode takes the parent's slot
+			}
+		}
+		for(int64_t s = 0; s < ns; ++ s)
+			if(s == 0 || !merged_into_next[s - 1])
+				first2.push_back(sn_first[s]);
+		sn_first.swap(first2);
+		for(size_t s = 0; s < sn_first.size(); ++ s) {
+			int32_t e = (s + 1 < sn_first.size()) ? sn_first[s + 1] : (int32_t)nb;
+			for(int32_t c = sn_first[s]; c < e; ++ c)
+				sn_of[c] = (int32_t)s;
+		}
+	}
+	const int64_t ns = (int64_t)sn_first.size();
+	sp->n_snodes = ns;
+
+	// ---- 4. per supernode: block row structure (own columns, then the union of the rows beyond)
+	std::vector<int32_t> pdim(nb);
+	std::vector<int64_t> pbase(nb + 1, 0);
+	for(int64_t k = 0; k < nb; ++ k) {
+		pdim[k] = st.dim[order[k]];
+		pbase[k + 1] = pbase[k] + pdim[k];
+	}
+	std::vector<std::vector<int32_t> > sn_rows(ns); // block columns of the front, ascending
+	std::vector<int32_t> sn_parent(ns, -1), sn_ncols(ns);
+	for(int64_t s = 0; s < ns; ++ s) {
+		const int32_t c0 = sn_first[s], c1 = (s + 1 < ns) ? sn_first[s + 1] : (int32_t)nb;
+		sn_ncols[s] = c1 - c0;
+		std::vector<int32_t> &r = sn_rows[s];
+		for(int32_t c = c0; c < c1; ++ c)
+			r.push_back(c);
+		std::vector<int32_t> beyond;
+		for(int32_t c = c0; c < c1; ++ c)
+			for(size_t q = 0; q < rstruct[c].size(); ++ q)
+				if(rstruct[c][q] >= c1)
+					beyond.push_back(rstruct[c][q]);
+		std::sort(beyond.begin(), beyond.end());
+		beyond.erase(std::unique(beyond.begin(), beyond.end()), beyond.end());
+		r.insert(r.end(), beyond.begin(), beyond.end());
+		if(!beyond.empty())
+			sn_parent[s] = sn_of[beyond[0]];
+	}
+
+	// ---- 5. levels of the assembly tree
+	std::vector<int32_t> level(ns, 0);
+	int32_t max_level = 0;
+	for(int64_t s = 0; s < ns; ++ s) { // children precede parents (postorder)
+		if(sn_parent[s] >= 0) {
+			SPP_REQUIRE(sn_parent[s] > s, SPP_E_HIP, "internal: supernode order");
+			level[sn_parent[s]] = std::max(level[sn_parent[s]], level[s] + 1);
+		}
+		max_level = std::max(max_level, level[s]);
+	}
+	sp->n_levels = max_level + 1;
+	sp->h_level_ptr.assign(sp->n_levels + 1, 0);
+	for(int64_t s = 0; s < ns; ++ s)
+		++ sp->h_level_ptr[level[s] + 1];
+	for(int64_t l = 0; l < sp->n_levels; ++ l)
+		sp->h_level_ptr[l + 1] += sp->h_level_ptr[l];
+	sp->h_level_fronts.resize(ns);
+	{
+		std::vector<int32_t> fill(sp->h_level_ptr.begin(), sp->h_level_ptr.end() - 1);
+		for(int64_t s = 0; s < ns; ++ s)
+			sp->h_level_fronts[fill[level[s]] ++] = (int32_t)s;
+	}
+
+	// ---- 6. flat arrays
+	std::vector<int32_t> front_h(ns), front_w(ns), front_ld(ns), rows_ptr(ns + 1, 0), rows;
+	std::vector<int64_t> front_off(ns), front_voff(ns);
+	std::vector<std::vector<int32_t> > loc_off(ns); // local scalar offset of each block row of the front
+	int64_t foff = 0, voff = 0;
+	double flops = 0;
+	int64_t nnz_r = 0;
+	for(int64_t s = 0; s < ns; ++ s) {
+		int32_t h = 0, w = 0;
+		loc_off[s].resize(sn_rows[s].size() + 1);
+		for(size_t q = 0; q < sn_rows[s].size(); ++ q) {
+			loc_off[s][q] = h;
+			h += pdim[sn_rows[s][q]];
+			if((int32_t)q < sn_ncols[s])
+				w = h;
+		}
+		loc_off[s][sn_rows[s].size()] = h;
+		SPP_REQUIRE(h < 32768, SPP_E_UNSUPPORTED, "front too large for 16-bit local indices");
+		front_h[s] = h;
+		front_w[s] = w;
+		front_ld[s] = (h + 1) & ~1; // even: 16-byte aligned columns
+		front_off[s] = foff;
+		foff += (int64_t)front_ld[s] * h;
+		foff = (foff + 1) & ~int64_t(1);
+		front_voff[s] = voff;
+		voff += h;
+		rows_ptr[s + 1] = rows_ptr[s] + h;
+		for(size_t q = 0; q < sn_rows[s].size(); ++ q)
+			for(int32_t e = 0; e < pdim[sn_rows[s][q]]; ++ e)
+				rows.push_back((int32_t)(pbase[sn_rows[s][q]] + e));
+		// flops of the partial factorization: sum over pivots of (remaining width)^2
+		for(int32_t j = 0; j < w; ++ j)
+			flops += (double)(h - j) * (double)(h - j);
+		nnz_r += (int64_t)w * h - (int64_t)w * (w - 1) / 2;
+	}
+	sp->front_doubles = foff;
+	sp->vbuf_doubles = voff;
+	sp->h_front_h = front_h;
+	sp->h_front_w = front_w;
+	sp->h_front_off = front_off;
+	ctx->factor_flops = (int64_t)flops;
+	ctx->factor_nnz = nnz_r;
+	ctx->solve_bytes = 8 * (st.nvals + nnz_r) + 16 * nnz_r + 16 * st.n; // factor + two tri-solves
+
+	// children lists and relative index maps
+	std::vector<int32_t> child_ptr(ns + 1, 0), child_list(ns), rel_ptr(ns + 1, 0), rel;
+	for(int64_t s = 0; s < ns; ++ s)
+		if(sn_parent[s] >= 0)
+			++ child_ptr[sn_parent[s] + 1];
+	for(int64_t s = 0; s < ns; ++ s)
+		child_ptr[s + 1] += child_ptr[s];
+	{
+		std::vector<int32_t> fill(child_ptr.begin(), child_ptr.end() - 1);
+		for(int64_t s = 0; s < ns; ++ s)
+			if(sn_parent[s] >= 0)
+				child_list[fill[sn_parent[s]] ++] = (int32_t)s;
+	}
+	child_list.resize(child_ptr[ns]);
+	for(int64_t s = 0; s < ns; ++ s) {
+		rel_ptr[s + 1] = rel_ptr[s];
+		const int32_t p = sn_parent[s];
+		if(p < 0)
+			continue;
+		const std::vector<int32_t> &pr = sn_rows[p];
+		size_t qp = 0;
+		for(size_t q = sn_ncols[s]; q < sn_rows[s].size(); ++ q) {
+			const int32_t g = sn_rows[s][q];
+			while(qp < pr.size() && pr[qp] < g)
+				++ qp;
+			SPP_REQUIRE(qp < pr.size() && pr[qp] == g, SPP_E_HIP, "internal: child row missing in parent front");
+			for(int32_t e = 0; e < pdim[g]; ++ e)
+				rel.push_back(loc_off[p][qp] + e);
+		}
+		rel_ptr[s + 1] = (int32_t)rel.size();
+	}
+
+	// assembly lists: every stored block of Lambda goes to the front owning its (permuted) row
+	std::vector<std::vector<int64_t> > a_src(ns);
+	std::vector<std::vector<int32_t> > a_dst(ns), a_shape(ns);
+	for(int64_t j = 0; j < nb; ++ j)
+		for(int64_t p = st.col_ptr[j]; p < st.col_ptr[j + 1]; ++ p) {
+			const int64_t i = st.row_idx[p];
+			int64_t a = inv[i], b = inv[j];
+			int tr = 0;
+			if(a > b) {
+				std::swap(a, b);
+				tr = 1; // the stored block is (i, j) = (b, a) in permuted terms: transpose into (a, b)
+			}
+			const int32_t s = sn_of[a];
+			const std::vector<int32_t> &r = sn_rows[s];
+			const size_t qa = (size_t)(a - sn_first[s]);
+			const size_t qb = (size_t)(std::lower_bound(r.begin(), r.end(), (int32_t)b) - r.begin());
+			SPP_REQUIRE(qb < r.size() && r[qb] == b, SPP_E_HIP, "internal: block outside of its front");
+			a_src[s].push_back((st.blk_off[p] << 1) | tr);
+			a_dst[s].push_back(loc_off[s][qa] | (loc_off[s][qb] << 16));
+			// shape of the destination sub-block (rows x cols)
+			a_shape[s].push_back(pdim[a] | (pdim[b] << 8));
+		}
+	std::vector<int32_t> asm_ptr(ns + 1, 0), asm_dst, asm_shape;
+	std::vector<int64_t> asm_src;
+	for(int64_t s = 0; s < ns; ++ s) {
+		asm_ptr[s + 1] = asm_ptr[s] + (int32_t)a_src[s].size();
+		asm_src.insert(asm_src.end(), a_src[s].begin(), a_src[s].end());
+		asm_dst.insert(asm_dst.end(), a_dst[s].begin(), a_dst[s].end());
+		asm_shape.insert(asm_shape.end(), a_shape[s].begin(), a_shape[s].end());
+	}
+	std::vector<int32_t> perm_scalar(st.n);
+	for(int64_t k = 0; k < nb; ++ k)
+		for(int32_t e = 0; e < pdim[k]; ++ e)
+			perm_scalar[pbase[k] + e] = (int32_t)(st.base[order[k]] + e);
+
+	hipStream_t s = ctx->stream;
+	sp->level_fronts.upload(sp->h_level_fronts, s);
+	sp->front_off.upload(front_off, s);
+	sp->front_h.upload(front_h, s);
+	sp->front_w.upload(front_w, s);
+	sp->front_ld.upload(front_ld, s);
+	sp->front_voff.upload(front_voff, s);
+	sp->asm_ptr.upload(asm_ptr, s);
+	sp->asm_src.upload(asm_src, s);
+	sp->asm_dst.upload(asm_dst, s);
+	sp->asm_shape.upload(asm_shape, s);
+	sp->child_ptr.upload(child_ptr, s);
+	sp->child_list.upload(child_list, s);
+	sp->rel_ptr.upload(rel_ptr, s);
+	sp->rel.upload(rel, s);
+	sp->rows_ptr.upload(rows_ptr, s);
+	sp->rows.upload(rows, s);
+	sp->perm_scalar.upload(perm_scalar, s);
+	sp->fronts.reserve((size_t)std::max<int64_t>(foff, 2));
+	sp->vbuf.reserve((size_t)std::max<int64_t>(voff, 1));
+	sp->xperm.reserve((size_t)st.n);
+	sp->info.reserve(4);
+	SPP_HIP_CHECK(hipStreamSynchronize(s));
+	(void)BIG_FRONT_H;
+}
+
+// --------------------------------------------------------------------------------------------------
+// kernels: one workgroup (256 threads) per front
+// --------------------------------------------------------------------------------------------------
+constexpr int FT = 256;
+
+__global__ __launch_bounds__(FT)
+void front_factor_kernel(const int32_t *__restrict__ level_fronts, const int64_t *__restrict__ front_off,
+	const int32_t *__restrict__ front_h, const int32_t *__restrict__ front_w, const int32_t *__restrict__ front_ld,
+	const int32_t *__restrict__ asm_ptr, const int64_t *__restrict__ asm_src, const int32_t *__restrict__ asm_dst,
+	const int32_t *__restrict__ asm_shape, const int32_t *__restrict__ child_ptr, const int32_t *__restrict__ child_list,
+	const int32_t *__restrict__ rel_ptr, const int32_t *__restrict__ rel, const double *__restrict__ vals,
+	double *__restrict__ fronts, int *__restrict__ info)
+{
+	const int s = level_fronts[blockIdx.x];
+	const int h = front_h[s], w = front_w[s], ld = front_ld[s];
+	double *F = fronts + front_off[s];
+	const int tid = threadIdx.x;
+	__shared__ double rowj[2048 + 8]; // staged pivot row (h <= 2048 fast path; else read from global)
+	__shared__ double pinv_s;
+	// ---- zero the upper triangle (column-wise, coalesced)
+	for(int64_t e = tid; e < (int64_t)ld * h; e += FT)
+		F[e] = 0.0;
+	__syncthreads();
+	// ---- blocks of Lambda
+	for(int q = asm_ptr[s]; q < asm_ptr[s + 1]; ++ q) {
+		const int64_t so = asm_src[q];
+		const double *src = vals + (so >> 1);
+		const int dr = asm_dst[q] & 0xffff, dc = asm_dst[q] >> 16;
+		const int nr = asm_shape[q] & 0xff, ncol = asm_shape[q] >> 8;
+		if(tid < nr * ncol) {
+			const int r = tid % nr, c = tid / nr;
+			// destination (r, c) of an nr x ncol block; source is nr x ncol col-major, or its
+			// transpose (ncol x nr col-major) when the permutation flipped the block
+			const double v = (so & 1) ? src[c + ncol * r] : src[r + nr * c];
+			F[(dr + r) + (int64_t)(dc + c) * ld] = v;
+		}
+	}
+	__syncthreads();
+	// ---- extend-add of the children's update matrices, children in list order
+	for(int cq = child_ptr[s]; cq < child_ptr[s + 1]; ++ cq) {
+		const int c = child_list[cq];
+		const int hc = front_h[c], wc = front_w[c], ldc = front_ld[c];
+		const double *Fc = fronts + front_off[c];
+		const int32_t *rl = rel + rel_ptr[c];
+		const int m = hc - wc;
+		// upper triangle of the m x m update block: (i <= j)
+		for(int64_t e = tid; e < (int64_t)m * m; e += FT) {
+			const int i = (int)(e % m), j = (int)(e / m);
+			if(i <= j)
+				F[rl[i] + (int64_t)rl[j] * ld] += Fc[(wc + i) + (int64_t)(wc + j) * ldc];
+		}
+		__syncthreads();
+	}
+	// ---- partial factorization, square-root free (one scaling pass at the end)
+	for(int j = 0; j < w; ++ j) {
+		// stage row j (columns j .. h-1)
+		for(int c = j + tid; c < h; c += FT)
+			rowj[(c - j) & 2047] = F[j + (int64_t)c * ld];
+		if(h - j > 2048) { /* very large front: rows are read from global below */ }
+		__syncthreads();
+		const double p = rowj[0];
+		if(!(p > 0)) {
+			if(tid == 0)
+				atomicMax(info, 1);
+			return; // uniform
+		}
+		const double pinv = 1.0 / p;
+		const int m = h - j - 1; // trailing size
+		// element (i, c), j < i <= c < h ; threads sweep columns, consecutive threads on consecutive rows
+		if(h - j <= 2048) {
+			for(int64_t e = tid; e < (int64_t)m * m; e += FT) {
+				const int i = (int)(e % m), c = (int)(e / m);
+				if(i <= c)
+					F[(j + 1 + i) + (int64_t)(j + 1 + c) * ld] -= rowj[1 + i] * pinv * rowj[1 + c];
+			}
+		} else {
+			for(int64_t e = tid; e < (int64_t)m * m; e += FT) {
+				const int i = (int)(e % m), c = (int)(e / m);
+				if(i <= c)
+					F[(j + 1 + i) + (int64_t)(j + 1 + c) * ld] -=
+						F[j + (int64_t)(j + 1 + i) * ld] * pinv * F[j + (int64_t)(j + 1 + c) * ld];
+			}
+		}
+		__syncthreads();
+	}
+	(void)pinv_s;
+	// ---- scale the pivot rows: R[j][c] = F[j][c] / sqrt(p_j)
+	for(int64_t e = tid; e < (int64_t)w * h; e += FT) {
+		const int j = (int)(e % w), c = (int)(e / w);
+		if(c > j)
+			F[j + (int64_t)c * ld] *= 1.0 / sqrt(F[j + (int64_t)j * ld]);
+	}
+	__syncthreads();
+	for(int j = tid; j < w; j += FT)
+		F[j + (int64_t)j * ld] = sqrt(F[j + (int64_t)j * ld]);
+}
+
+// forward substitution R^T y = b, leaves -> root. v = work vector of the front (length h).
+__global__ __launch_bounds__(FT)
+void front_fwd_kernel(const int32_t *__restrict__ level_fronts, const int64_t *__restrict__ front_off,
+	const int32_t *__restrict__ front_h, const int32_t *__restrict__ front_w, const int32_t *__restrict__ front_ld,
+	const int64_t *__restrict__ front_voff, const int32_t *__restrict__ child_ptr, const int32_t *__restrict__ child_list,
+	const int32_t *__restrict__ rel_ptr, const int32_t *__restrict__ rel, const int32_t *__restrict__ rows_ptr,
+	const int32_t *__restrict__ rows, const double *__restrict__ fronts, double *__restrict__ vbuf,
+	double *__restrict__ xperm)
+{
+	const int s = level_fronts[blockIdx.x];
+	const int h = front_h[s], w = front_w[s], ld = front_ld[s];
+	const double *F = fronts + front_off[s];
+	double *v = vbuf + front_voff[s];
+	const int32_t *rw = rows + rows_ptr[s];
+	const int tid = threadIdx.x;
+	for(int c = tid; c < h; c += FT)
+		v[c] = (c < w) ? xperm[rw[c]] : 0.0;
+	__syncthreads();
+	for(int cq = child_ptr[s]; cq < child_ptr[s + 1]; ++ cq) {
+		const int c = child_list[cq];
+		const int hc = front_h[c], wc = front_w[c];
+		const double *vc = vbuf + front_voff[c];
+		const int32_t *rl = rel + rel_ptr[c];
+		for(int i = tid; i < hc - wc; i += FT)
+			v[rl[i]] += vc[wc + i];
+		__syncthreads();
+	}
+	for(int j = 0; j < w; ++ j) {
+		const double yj = v[j] / F[j + (int64_t)j * ld];
+		__syncthreads(); // everyone has read v[j] before it is overwritten / used
+		if(tid == 0)
+			v[j] = yj;
+		for(int c = j + 1 + tid; c < h; c += FT)
+			v[c] -= F[j + (int64_t)c * ld] * yj;
+		__syncthreads();
+	}
+	for(int c = tid; c < w; c += FT)
+		xperm[rw[c]] = v[c];
+}
+
+// backward substitution R x = y, root -> leaves
+__global__ __launch_bounds__(FT)
+void front_bwd_kernel(const int32_t *__restrict__ level_fronts, const int64_t *__restrict__ front_off,
+	const int32_t *__restrict__ front_h, const int32_t *__restrict__ front_w, const int32_t *__restrict__ front_ld,
+	const int64_t *__restrict__ front_voff, const int32_t *__restrict__ rows_ptr, const int32_t *__restrict__ rows,
+	const double *__restrict__ fronts, double *__restrict__ vbuf, double *__restrict__ xperm)
+{
+	const int s = level_fronts[blockIdx.x];
+	const int h = front_h[s], w = front_w[s], ld = front_ld[s];
+	const double *F = fronts + front_off[s];
+	double *v = vbuf + front_voff[s];
+	const int32_t *rw = rows + rows_ptr[s];
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	__shared__ double red[FT / 64];
+	for(int c = tid; c < h; c += FT)
+		v[c] = xperm[rw[c]]; // own part: y ; beyond: final x of the ancestors
+	__syncthreads();
+	for(int j = w; j > 0;) {
+		-- j;
+		double sum = 0;
+		for(int c = j + 1 + tid; c < h; c += FT)
+			sum += F[j + (int64_t)c * ld] * v[c];
+#pragma unroll
+		for(int off = 32; off > 0; off >>= 1)
+			sum += __shfl_xor(sum, off);
+		if(lane == 0)
+			red[wave] = sum;
+		__syncthreads();
+		if(tid == 0) {
+			double t = 0;
+			for(int q = 0; q < FT / 64; ++ q)
+				t += red[q];
+			v[j] = (v[j] - t) / F[j + (int64_t)j * ld];
+		}
+		__syncthreads();
+	}
+	for(int c = tid; c < w; c += FT)
+		xperm[rw[c]] = v[c];
+}
+
+__global__ void gather_perm_kernel(int64_t n, const int32_t *__restrict__ perm, const double *__restrict__ src,
+	double *__restrict__ dst)
+{
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if(i < n)
+		dst[i] = src[perm[i]];
+}
+
+__global__ void scatter_perm_kernel(int64_t n, const int32_t *__restrict__ perm, const double *__restrict__ src,
+	double *__restrict__ dst)
+{
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if(i < n)
+		dst[perm[i]] = src[i];
+}
+
+__global__ void zero_info_kernel(int *info) { info[0] = 0; }
+
+int sparse_factor_solve(spp_ctx *ctx, const double *d_vals, double *d_rhs)
+{
+	SparsePlan *sp = ctx->sparse;
+	SPP_REQUIRE(sp, SPP_E_STATE, "sparse plan missing");
+	hipStream_t s = ctx->stream;
+	const unsigned gn = (unsigned)((sp->n + 255) / 256);
+	hipLaunchKernelGGL(zero_info_kernel, dim3(1), dim3(1), 0, s, sp->info.p);
+	phase_begin(ctx, SPP_PHASE_FACTOR);
+	for(int64_t l = 0; l < sp->n_levels; ++ l) {
+		const int32_t b = sp->h_level_ptr[l], e = sp->h_level_ptr[l + 1];
+		hipLaunchKernelGGL(front_factor_kernel, dim3((unsigned)(e - b)), dim3(FT), 0, s,
+			sp->level_fronts.p + b, sp->front_off.p, sp->front_h.p, sp->front_w.p, sp->front_ld.p,
+			sp->asm_ptr.p, sp->asm_src.p, sp->asm_dst.p, sp->asm_shape.p, sp->child_ptr.p, sp->child_list.p,
+			sp->rel_ptr.p, sp->rel.p, d_vals, sp->fronts.p, sp->info.p);
+	}
+	phase_end(ctx, SPP_PHASE_FACTOR);
+	SPP_HIP_CHECK(hipGetLastError());
+	int h_info = 0;
+	SPP_HIP_CHECK(hipMemcpyAsync(&h_info, sp->info.p, sizeof(int), hipMemcpyDeviceToHost, s));
+	SPP_HIP_CHECK(hipStreamSynchronize(s));
+	if(h_info)
+		return SPP_NOT_POSDEF;
+	phase_begin(ctx, SPP_PHASE_TRISOLVE);
+	hipLaunchKernelGGL(gather_perm_kernel, dim3(gn), dim3(256), 0, s, sp->n, sp->perm_scalar.p, d_rhs, sp->xperm.p);
+	for(int64_t l = 0; l < sp->n_levels; ++ l) {
+		const int32_t b = sp->h_level_ptr[l], e = sp->h_level_ptr[l + 1];
+		hipLaunchKernelGGL(front_fwd_kernel, dim3((unsigned)(e - b)), dim3(FT), 0, s,
+			sp->level_fronts.p + b, sp->front_off.p, sp->front_h.p, sp->front_w.p, sp->front_ld.p, sp->front_voff.p,
+			sp->child_ptr.p, sp->child_list.p, sp->rel_ptr.p, sp->rel.p, sp->rows_ptr.p, sp->rows.p,
+			sp->fronts.p, sp->vbuf.p, sp->xperm.p);
+	}
+	for(int64_t l = sp->n_levels; l > 0;) {
+		-- l;
+		const int32_t b = sp->h_level_ptr[l], e = sp->h_level_ptr[l + 1];
+		hipLaunchKernelGGL(front_bwd_kernel, dim3((unsigned)(e - b)), dim3(FT), 0, s,
+			sp->level_fronts.p + b, sp->front_off.p, sp->front_h.p, sp->front_w.p, sp->front_ld.p, sp->front_voff.p,
+			sp->rows_ptr.p, sp->rows.p, sp->fronts.p, sp->vbuf.p, sp->xperm.p);
+	}
+	hipLaunchKernelGGL(scatter_perm_kernel, dim3(gn), dim3(256), 0, s, sp->n, sp->perm_scalar.p, sp->xperm.p, d_rhs);
+	phase_end(ctx, SPP_PHASE_TRISOLVE);
+	SPP_HIP_CHECK(hipGetLastError());
+	return SPP_OK;
+}
+
+} // namespace spp

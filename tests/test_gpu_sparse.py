@@ -1,0 +1,105 @@
+"""GPU parity of the sparse (pose graph) path: supernodal multifrontal block Cholesky + triangular
+solves through the C ABI, against the CPU oracle's restatement of CLinearSolver_UberBlock and the
+reference's own backends (oracle/_ref) when present.
+
+Tolerance. north_star asks for ||dx_gpu - dx_ref|| / ||dx_ref|| < 1e-10. Pose graphs anchored by the
+unit unary factor alone are ill-conditioned (cond 1e9..1e11 for the synthetic configs); on them the
+reference's OWN backends (UberBlock / CSparse / CHOLMOD) disagree with each other by 1e-9..1e-8, so
+no solver can be within 1e-10 of "the" reference. The test therefore demands
+    rel. diff <= max(1e-10, 4 x the largest pairwise spread among the reference backends)
+plus a backward-error bound (relative residual <= 1e-11) that does not depend on conditioning,
+and checks the plain 1e-10 bound on a well-conditioned variant (strong prior on the first pose)."""
+import numpy as np
+import pytest
+
+from slam_plus_plus_amd import api, synth
+from oracle import spp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return np.linalg.norm(a - b) / np.linalg.norm(b)
+
+
+def _ref_solutions(lam, eta):
+    out = {}
+    if orc.have_ref():
+        for be in ("uberblock", "csparse", "cholmod"):
+            st, x, _ = orc.RefSolver(be, lam).solve(lam.vals, eta)
+            assert st == 0
+            out[be] = x
+    st, xo = orc.solve_blocky(lam, eta)
+    assert st == 0
+    out["oracle"] = xo
+    return out
+
+
+def _spread(sols):
+    keys = list(sols)
+    return max([_rel(sols[a], sols[b]) for i, a in enumerate(keys) for b in keys[i + 1:]] + [0.0])
+
+
+@pytest.mark.parametrize("name", ["se2_small", "se3_small", "manhattan3500", "sphere2500"])
+def test_sparse_solve_matches_reference(name):
+    prob = synth.make(name)
+    lam, eta = orc.assemble(prob)
+    solver = api.CLinearSolver_HIP(mode=api.MODE_AUTO)
+    x = eta.copy()
+    assert solver.Solve_PosDef_Blocky(lam, x)
+    assert solver.ctx.info("MODE") == api.MODE_SPARSE
+    res = np.linalg.norm(lam.matvec(x) - eta) / np.linalg.norm(eta)
+    assert res < 1e-11, res
+    sols = _ref_solutions(lam, eta)
+    tol = max(1e-10, 4 * _spread(sols))
+    for k, xr in sols.items():
+        assert _rel(x, xr) < tol, (k, _rel(x, xr), tol)
+    x2 = eta.copy()
+    assert solver.Solve_PosDef_Blocky(lam, x2)
+    assert np.array_equal(x, x2), "factorization must be bit-reproducible"
+
+
+@pytest.mark.parametrize("name", ["se2_small", "se3_small", "manhattan3500"])
+def test_sparse_solve_1e10_when_well_conditioned(name):
+    prob = synth.make(name)
+    lam, eta = orc.assemble(prob, damping=50.0)  # LM-style damping: cond drops to ~1e4
+    solver = api.CLinearSolver_HIP(mode=api.MODE_SPARSE)
+    x = eta.copy()
+    assert solver.Solve_PosDef_Blocky(lam, x)
+    sols = _ref_solutions(lam, eta)
+    for k, xr in sols.items():
+        assert _rel(x, xr) < 1e-10, (k, _rel(x, xr))
+
+
+def test_sparse_mode_on_ba_system_matches_schur_mode():
+    """the same Lambda through both paths (the reference can do this too: -us on/off)"""
+    prob = synth.make("ba_small")
+    lam, eta = orc.assemble(prob)
+    a = api.CLinearSolver_HIP(mode=api.MODE_SPARSE)
+    b = api.CLinearSolver_HIP(mode=api.MODE_SCHUR)
+    xa, xb = eta.copy(), eta.copy()
+    assert a.Solve_PosDef_Blocky(lam, xa) and b.Solve_PosDef_Blocky(lam, xb)
+    assert _rel(xa, xb) < 1e-10
+
+
+def test_ordering_is_a_permutation_and_fill_is_sane():
+    prob = synth.make("manhattan3500")
+    lam, eta = orc.assemble(prob)
+    s = api.CLinearSolver_HIP(mode=api.MODE_SPARSE)
+    s.SymbolicDecomposition_Blocky(lam)
+    order = s.ctx.ordering(lam.nb)
+    assert np.array_equal(np.sort(order), np.arange(lam.nb))
+    nnz = s.ctx.info("FACTOR_NNZ")
+    assert nnz < 40 * lam.nvals, "fill-in exploded: ordering broken"
+
+
+def test_not_posdef_returns_false():
+    prob = synth.make("se2_small")
+    lam, eta = orc.assemble(prob)
+    vals = lam.vals.copy()
+    p = lam.col_ptr[101] - 1
+    vals[lam.blk_off[p]:lam.blk_off[p] + 9] = -np.eye(3).ravel()
+    s = api.CLinearSolver_HIP(mode=api.MODE_SPARSE)
+    x = eta.copy()
+    assert s.Solve_PosDef_Blocky(lam.with_vals(vals), x) is False
+    assert np.array_equal(x, eta)
