@@ -143,6 +143,8 @@ int spp_device_malloc(spp_ctx *ctx, size_t bytes, void **d_ptr);
 int spp_device_free(spp_ctx *ctx, void *d_ptr);
 int spp_memcpy_h2d(spp_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 int spp_memcpy_d2h(spp_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+/* asynchronous on the ctx stream */
+int spp_memcpy_d2d(spp_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);
 
 /* ---- profiling (SPP_FLAG_PROFILE) ------------------------------------------------------------------
  * phase names follow the reference's __SCHUR_PROFILING / Dump() vocabulary

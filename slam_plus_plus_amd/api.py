@@ -30,7 +30,7 @@ EXPORTS = [
     "spp_analyze", "spp_set_shard", "spp_get_info", "spp_get_ordering", "spp_factor_solve",
     "spp_factor_solve_device", "spp_schur_buffer_size", "spp_schur_form", "spp_schur_finish",
     "spp_assemble_analyze", "spp_assemble_get_structure", "spp_assemble_device", "spp_device_malloc",
-    "spp_device_free", "spp_memcpy_h2d", "spp_memcpy_d2h", "spp_get_phase_ms", "spp_get_dominant_kernel",
+    "spp_device_free", "spp_memcpy_h2d", "spp_memcpy_d2h", "spp_memcpy_d2d", "spp_get_phase_ms", "spp_get_dominant_kernel",
     "spp_microbench_copy", "spp_microbench_mfma_f64", "spp_dense_potrf_upper", "spp_dense_posv",
     "spp_dense_gemm_tn_sub", "spp_version",
 ]
@@ -77,6 +77,7 @@ def load_library():
         "spp_device_free": (cint, [vp, vp]),
         "spp_memcpy_h2d": (cint, [vp, vp, vp, ctypes.c_size_t]),
         "spp_memcpy_d2h": (cint, [vp, vp, vp, ctypes.c_size_t]),
+        "spp_memcpy_d2d": (cint, [vp, vp, vp, ctypes.c_size_t]),
         "spp_get_phase_ms": (cint, [vp, _c_f64p]),
         "spp_get_dominant_kernel": (cint, [vp, _c_f64p, _c_i64p, _c_f64p]),
         "spp_microbench_copy": (cint, [vp, ctypes.c_size_t, cint, _c_f64p]),
@@ -123,6 +124,11 @@ class DeviceArray:
         out = np.empty(self.n, dtype=self.dtype)
         self.ctx._check(self.ctx.lib.spp_memcpy_d2h(self.ctx.h, _ptr(out), self.ptr, out.nbytes))
         return out
+
+    def copy_from(self, other):
+        """asynchronous device-to-device copy on the ctx stream"""
+        assert other.n * other.dtype.itemsize <= self.n * self.dtype.itemsize
+        self.ctx._check(self.ctx.lib.spp_memcpy_d2d(self.ctx.h, self.ptr, other.ptr, other.n * other.dtype.itemsize))
 
     def free(self):
         if self.ptr:

@@ -452,6 +452,17 @@ int spp_memcpy_d2h(spp_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)
 	SPP_CATCH(ctx)
 }
 
+int spp_memcpy_d2d(spp_ctx *ctx, void *d_dst, const void *d_src, size_t bytes)
+{
+	if(!ctx)
+		return SPP_E_BADARG;
+	SPP_TRY(ctx)
+	SPP_HIP_CHECK(hipSetDevice(ctx->device));
+	SPP_HIP_CHECK(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+	return SPP_OK;
+	SPP_CATCH(ctx)
+}
+
 int spp_get_phase_ms(spp_ctx *ctx, double *ms_out)
 {
 	if(!ctx || !ms_out)
