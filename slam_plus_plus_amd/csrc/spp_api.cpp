@@ -138,6 +138,11 @@ void spp_destroy(spp_ctx *ctx)
 		return;
 	spp_free_memory(ctx);
 	ctx->dense.info.release();
+	if(ctx->dense.aux) {
+		(void)hipStreamDestroy(ctx->dense.aux);
+		(void)hipEventDestroy(ctx->dense.ev[0]);
+		(void)hipEventDestroy(ctx->dense.ev[1]);
+	}
 	if(ctx->timer.created)
 		for(int i = 0; i < 2 * SPP_N_PHASES; ++ i)
 			(void)hipEventDestroy(ctx->timer.ev[i]);

@@ -28,6 +28,7 @@
 // CONSECUTIVE ROWS of C: every store/load of C touches whole 128-byte segments of a column.
 
 #include "spp_internal.h"
+#include <stdlib.h>
 
 namespace spp {
 
@@ -62,14 +63,26 @@ void gemm_tn_kernel(int64_t M, int64_t N, int K, const double *__restrict__ A, i
 	const int l15 = lane & 15, l4 = lane >> 4;
 
 	v4f64 acc[TB][TA];
+	// MODE 0: the old C values are fetched up front (their latency hides under the whole k-loop) and
+	// folded in as the initial accumulator: acc = -C, C_new = -(acc + A^T B)
 #pragma unroll
 	for(int b = 0; b < TB; ++ b)
 #pragma unroll
-		for(int a = 0; a < TA; ++ a)
+		for(int a = 0; a < TA; ++ a) {
 			acc[b][a] = (v4f64){0, 0, 0, 0};
+			if(MODE == 0) {
+				const int64_t m = m0 + wm + a * 16 + l15;
+#pragma unroll
+				for(int r = 0; r < 4; ++ r) {
+					const int64_t n = n0 + wn + b * 16 + l4 + 4 * r;
+					if(m < M && n < N)
+						acc[b][a][r] = -C[m + n * ldc];
+				}
+			}
+		}
 
-	// global staging: piece p -> (column p / 8, 16-byte piece p % 8)
-	double2 ra[PA], rb[PB];
+	// global staging: piece p -> (column p / 8, 16-byte piece p % 8); two slabs in flight
+	double2 ra[2][PA], rb[2][PB];
 	const double *pa[PA], *pb[PB];
 #pragma unroll
 	for(int i = 0; i < PA; ++ i) {
@@ -85,50 +98,49 @@ void gemm_tn_kernel(int64_t M, int64_t N, int K, const double *__restrict__ A, i
 		if(col > N - 1) col = N - 1;
 		pb[i] = B + col * ldb + (p & 7) * 2;
 	}
-#pragma unroll
-	for(int i = 0; i < PA; ++ i)
-		ra[i] = *(const double2*)(pa[i]);
-#pragma unroll
-	for(int i = 0; i < PB; ++ i)
-		rb[i] = *(const double2*)(pb[i]);
+#define SPP_LOAD_SLAB(buf, kofs) \
+	_Pragma("unroll") for(int i = 0; i < PA; ++ i) ra[buf][i] = *(const double2*)(pa[i] + (kofs)); \
+	_Pragma("unroll") for(int i = 0; i < PB; ++ i) rb[buf][i] = *(const double2*)(pb[i] + (kofs));
+#define SPP_STORE_SLAB(buf) \
+	_Pragma("unroll") for(int i = 0; i < PA; ++ i) { int p = tid + i * NT; \
+		*(double2*)(&As[(p >> 3) * LDS_STRIDE + (p & 7) * 2]) = ra[buf][i]; } \
+	_Pragma("unroll") for(int i = 0; i < PB; ++ i) { int p = tid + i * NT; \
+		*(double2*)(&Bs[(p >> 3) * LDS_STRIDE + (p & 7) * 2]) = rb[buf][i]; }
+#define SPP_COMPUTE_SLAB() \
+	_Pragma("unroll") for(int kk = 0; kk < BK / 4; ++ kk) { \
+		double fa[TA], fb[TB]; \
+		_Pragma("unroll") for(int a = 0; a < TA; ++ a) fa[a] = As[(wm + a * 16 + l15) * LDS_STRIDE + kk * 4 + l4]; \
+		_Pragma("unroll") for(int b = 0; b < TB; ++ b) fb[b] = Bs[(wn + b * 16 + l15) * LDS_STRIDE + kk * 4 + l4]; \
+		_Pragma("unroll") for(int b = 0; b < TB; ++ b) \
+			_Pragma("unroll") for(int a = 0; a < TA; ++ a) \
+				acc[b][a] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[b], fa[a], acc[b][a], 0, 0, 0); \
+	}
 
-	for(int k0 = 0; k0 < K; k0 += BK) {
+	SPP_LOAD_SLAB(0, 0)
+	if(BK < K) {
+		SPP_LOAD_SLAB(1, BK)
+	}
+	for(int k0 = 0; k0 < K; k0 += 2 * BK) {
 		__syncthreads(); // previous slab fully consumed
-#pragma unroll
-		for(int i = 0; i < PA; ++ i) {
-			int p = tid + i * NT;
-			*(double2*)(&As[(p >> 3) * LDS_STRIDE + (p & 7) * 2]) = ra[i];
-		}
-#pragma unroll
-		for(int i = 0; i < PB; ++ i) {
-			int p = tid + i * NT;
-			*(double2*)(&Bs[(p >> 3) * LDS_STRIDE + (p & 7) * 2]) = rb[i];
-		}
+		SPP_STORE_SLAB(0)
 		__syncthreads();
-		if(k0 + BK < K) { // prefetch the next slab into registers while the MFMAs run
-#pragma unroll
-			for(int i = 0; i < PA; ++ i)
-				ra[i] = *(const double2*)(pa[i] + k0 + BK);
-#pragma unroll
-			for(int i = 0; i < PB; ++ i)
-				rb[i] = *(const double2*)(pb[i] + k0 + BK);
+		if(k0 + 2 * BK < K) {
+			SPP_LOAD_SLAB(0, k0 + 2 * BK)
 		}
-#pragma unroll
-		for(int kk = 0; kk < BK / 4; ++ kk) {
-			double fa[TA], fb[TB];
-#pragma unroll
-			for(int a = 0; a < TA; ++ a)
-				fa[a] = As[(wm + a * 16 + l15) * LDS_STRIDE + kk * 4 + l4];
-#pragma unroll
-			for(int b = 0; b < TB; ++ b)
-				fb[b] = Bs[(wn + b * 16 + l15) * LDS_STRIDE + kk * 4 + l4];
-#pragma unroll
-			for(int b = 0; b < TB; ++ b)
-#pragma unroll
-				for(int a = 0; a < TA; ++ a)
-					acc[b][a] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[b], fa[a], acc[b][a], 0, 0, 0);
+		SPP_COMPUTE_SLAB()
+		if(k0 + BK < K) {
+			__syncthreads();
+			SPP_STORE_SLAB(1)
+			__syncthreads();
+			if(k0 + 3 * BK < K) {
+				SPP_LOAD_SLAB(1, k0 + 3 * BK)
+			}
+			SPP_COMPUTE_SLAB()
 		}
 	}
+#undef SPP_LOAD_SLAB
+#undef SPP_STORE_SLAB
+#undef SPP_COMPUTE_SLAB
 	if(MODE == 1)
 		__syncthreads(); // in-place: every wave has finished reading B before anyone writes C
 
@@ -141,13 +153,8 @@ void gemm_tn_kernel(int64_t M, int64_t N, int K, const double *__restrict__ A, i
 #pragma unroll
 			for(int r = 0; r < 4; ++ r) {
 				const int64_t n = n0 + wn + b * 16 + l4 + 4 * r;
-				if(m < M && n < N) {
-					double *c = C + m + n * ldc;
-					if(MODE == 0)
-						*c -= acc[b][a][r];
-					else
-						*c = acc[b][a][r];
-				}
+				if(m < M && n < N)
+					C[m + n * ldc] = (MODE == 0) ? -acc[b][a][r] : acc[b][a][r];
 			}
 		}
 }
@@ -174,7 +181,18 @@ void dense_gemm_tn_sub(spp_ctx *ctx, int64_t m, int64_t n, int64_t k, const doub
 	int64_t t128 = ((m + 127) / 128) * ((n + 127) / 128);
 	if(upper_only)
 		t128 = t128 / 2 + 1;
-	if(t128 >= 192)
+	static int cfg = -1;
+	if(cfg < 0) {
+		const char *e = getenv("SPP_GEMM_CFG");
+		cfg = e ? atoi(e) : 1;
+	}
+	if(t128 >= 192 && cfg == 1)
+		launch_gemm<128, 128, 64, 32, 0>(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc, upper_only);
+	else if(t128 >= 192 && cfg == 2)
+		launch_gemm<128, 128, 32, 64, 0>(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc, upper_only);
+	else if(t128 >= 192 && cfg == 3)
+		launch_gemm<128, 64, 64, 32, 0>(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc, upper_only);
+	else if(t128 >= 192)
 		launch_gemm<128, 128, 64, 64, 0>(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc, upper_only);
 	else
 		launch_gemm<64, 64, 32, 32, 0>(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc, upper_only);
@@ -182,76 +200,231 @@ void dense_gemm_tn_sub(spp_ctx *ctx, int64_t m, int64_t n, int64_t k, const doub
 }
 
 // --------------------------------------------------------------------------------------------------
-// potrf of one 128 x 128 diagonal block in LDS.
-//   in : T = upper triangle of the block (global, column-major, ld)
-//   out: upper triangle <- R_kk ; tinv (128 x 128, column-major, dense upper triangular) <- R_kk^-1
-// Square-root-free right-looking elimination (rows are scaled once at the end), so a pivot step
-// needs a single barrier. The strictly lower triangle of the LDS image accumulates G = (R^-1)^T:
-//   step j, row i > j, f = T[j][i] / p_j:
-//     c <  j : T[i][c] -= f * T[j][c]      (G update)
-//     c == j : T[i][j]  = -f               (new G entry; G[j][j] = 1 unscaled)
-//     c >= i : T[i][c] -= f * T[j][c]      (trailing update of the upper triangle)
-// n_valid < 128 marks the last (padded) block: rows/cols >= n_valid are never pivots; column
-// n_valid (if has_rhs) is carried along as a right-hand side.
+// potrf of one 128 x 128 diagonal block, entirely in LDS, blocked by 16 with MFMA f64 updates.
+//   in : T = upper triangle of the block (global, column-major, ld); padding rows/cols (>= n_valid)
+//        are exact identity; if has_rhs, column n_valid holds a right-hand side (rows < n_valid)
+//   out: upper triangle <- R_kk ; rhs column <- R_kk^-T rhs ;
+//        tinv (128 x 128 column-major, dense upper triangular) <- R_kk^-1
+// For each 16-wide panel J:
+//   A  (wave 0)   factor the 16 x 16 diagonal tile and invert it (square-root-free elimination whose
+//                 unused lower half accumulates (R_JJ^-1)^T, one wave, no workgroup barrier)
+//   B  (8 waves)  row panel: X = Dinv^T Y for the tiles right of the diagonal (R part) and left of it
+//                 (G part: the rows of (R^-1)^T accumulated in the unused LOWER triangle of the block)
+//   C  (8 waves)  trailing update T[I,K] -= P_I^T P_K (R part) and G[I,Cb] -= P_I^T G[J,Cb] (G part)
+// 3 workgroup barriers per panel instead of one per pivot.
 // info[0] = first failing global pivot index + 1 (non-positive pivot, Eigen's LLT test).
 // --------------------------------------------------------------------------------------------------
 constexpr int NB = DENSE_NB;
-constexpr int TS = NB + 1; // LDS row stride (column-major image: element (r, c) at r + c * TS)
+constexpr int TS = NB + 1;   // LDS column stride of the block image: element (r, c) at r + c * TS
+constexpr int PT = 17;       // column stride of the 16 x 16 scratch tiles
+constexpr int POTRF_THREADS = 512;
+constexpr int POTRF_LDS_DOUBLES = NB * TS + 3 * 16 * PT + 2 * NB + 8;
 
-__global__ __launch_bounds__(1024)
+// D (16 x 16) = sum_k A[k][i] * B[k][j], k = 0..15; A element (k, i) at a[k * aks + i * ais],
+// B element (k, j) at b[k * bks + j * bjs]. Result in the MFMA D layout (row (l>>4) + 4 r, col l & 15).
+__device__ __forceinline__ v4f64 tile_atb(const double *a, int aks, int ais, const double *b, int bks, int bjs, int lane)
+{
+	v4f64 acc = (v4f64){0, 0, 0, 0};
+	const int l15 = lane & 15, l4 = lane >> 4;
+#pragma unroll
+	for(int kk = 0; kk < 4; ++ kk) {
+		const double fa = a[(kk * 4 + l4) * aks + l15 * ais];
+		const double fb = b[(kk * 4 + l4) * bks + l15 * bjs];
+		acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, fb, acc, 0, 0, 0);
+	}
+	return acc;
+}
+
+__global__ __launch_bounds__(POTRF_THREADS)
 void potrf_diag_kernel(double *__restrict__ Ablk, int64_t ld, int n_valid, int has_rhs,
 	double *__restrict__ tinv, int *__restrict__ info, int64_t k0)
 {
-	extern __shared__ double T[]; // NB * TS doubles + NB pivots
-	double *piv = T + NB * TS;
-	const int tid = threadIdx.x;
-	for(int e = tid; e < NB * NB; e += 1024) {
-		int r = e & (NB - 1), c = e >> 7;
-		T[r + c * TS] = Ablk[r + (int64_t)c * ld];
+	extern __shared__ double sm[];
+	double *T = sm;                  // NB x NB image, stride TS
+	double *Dv = T + NB * TS;        // Dinv[k][i] at Dv[k + i * PT] (upper triangular, zeros below)
+	double *Gd = Dv + 16 * PT;       // G_JJ[r][c] = Dinv[c][r] at Gd[r + c * PT] (lower triangular incl. diagonal)
+	double *W = Gd + 16 * PT;        // work tile of step A
+	double *dinv = W + 16 * PT;      // 1 / R[j][j]
+	double *yv = dinv + NB;          // carried right-hand side
+	int *fail = (int*)(yv + NB);
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int l15 = lane & 15, l4 = lane >> 4;
+	{
+		// 16-byte loads, all 16 per thread in flight before the first LDS store
+		double2 v[NB * NB / 2 / POTRF_THREADS];
+#pragma unroll
+		for(int t = 0; t < NB * NB / 2 / POTRF_THREADS; ++ t) {
+			const int e = tid + t * POTRF_THREADS, r = (e & (NB / 2 - 1)) * 2, c = e >> 6;
+			v[t] = *(const double2*)(Ablk + r + (int64_t)c * ld);
+		}
+#pragma unroll
+		for(int t = 0; t < NB * NB / 2 / POTRF_THREADS; ++ t) {
+			const int e = tid + t * POTRF_THREADS, r = (e & (NB / 2 - 1)) * 2, c = e >> 6;
+			T[r + c * TS] = v[t].x;
+			T[r + 1 + c * TS] = v[t].y;
+		}
+	}
+	if(tid == 0)
+		*fail = 0;
+	__syncthreads();
+	const int rhs_col = (has_rhs && n_valid < NB) ? n_valid : -1;
+	if(tid < NB) {
+		yv[tid] = (rhs_col >= 0 && tid < n_valid) ? T[tid + rhs_col * TS] : 0.0;
+		dinv[tid] = 1.0;
 	}
 	__syncthreads();
-	const int ncol = has_rhs ? (n_valid + 1 < NB ? n_valid + 1 : NB) : n_valid; // columns carried along
-	// each thread owns rows i = tid >> 3 (+128 k... only 128 rows), column lanes (tid & 7) + 8 t
-	const int i = tid >> 3, cl = tid & 7;
-	bool failed = false;
-	for(int j = 0; j < n_valid; ++ j) {
-		const double p = T[j + j * TS];
-		if(!(p > 0)) {
-			failed = true; // uniform: every thread reads the same pivot
-			if(tid == 0)
-				info[0] = (int)(k0 + j + 1);
-			break;
+	if(rhs_col >= 0 && tid < NB)
+		T[tid + rhs_col * TS] = (tid == rhs_col) ? 1.0 : 0.0; // the rhs column becomes plain padding
+	__syncthreads();
+
+	for(int J = 0; J < NB / 16; ++ J) {
+		const int j0 = J * 16;
+		// ---- A: diagonal tile, wave 0, in registers: lane (c = l & 15, g = l >> 4) owns rows 4g..4g+3 of
+		// column c. Square-root-free elimination; the strictly lower half accumulates G = (R_JJ^-1)^T:
+		//   pivot j, row i > j, f = W[j][i] / p_j:  c < j : W[i][c] -= f W[j][c]   (G update)
+		//                                           c == j: W[i][j]  = -f          (new G entry)
+		//                                           c >= i: W[i][c] -= f W[j][c]   (trailing update)
+		// Cross-lane traffic per pivot: 5 double shuffles + 1 uniform broadcast; no LDS round trips.
+		if(wave == 0) {
+			double x[4];
+#pragma unroll
+			for(int t = 0; t < 4; ++ t) {
+				const int i = 4 * l4 + t;
+				x[t] = (i <= l15) ? T[(j0 + i) + (j0 + l15) * TS] : 0.0;
+			}
+			bool bad = false;
+#pragma unroll
+			for(int j = 0; j < 16; ++ j) {
+				const int src = j | ((j >> 2) << 4); // lane holding W[j][j] in register j & 3
+				const double p = __shfl(x[j & 3], src);
+				if(!(p > 0)) {
+					if(!bad && lane == 0) {
+						*fail = 1;
+						info[0] = (int)(k0 + j0 + j + 1);
+					}
+					bad = true;
+				}
+				const double pinv = 1.0 / p;
+				const double rowj_c = __shfl(x[j & 3], l15 | ((j >> 2) << 4)); // W[j][c]
+#pragma unroll
+				for(int t = 0; t < 4; ++ t) {
+					const int i = 4 * l4 + t;
+					const double f = __shfl(x[j & 3], i | ((j >> 2) << 4)) * pinv; // W[j][i] / p
+					const bool below = i > j;
+					const double upd = x[t] - f * rowj_c;
+					x[t] = (below && l15 == j) ? -f : ((below && (l15 < j || l15 >= i)) ? upd : x[t]);
+				}
+			}
+			if(!bad) {
+				double pv[4];
+#pragma unroll
+				for(int t = 0; t < 4; ++ t) {
+					const int i = 4 * l4 + t;
+					pv[t] = 1.0 / sqrt(__shfl(x[t], i | (l4 << 4))); // 1 / sqrt(W[i][i])
+				}
+#pragma unroll
+				for(int t = 0; t < 4; ++ t) {
+					const int i = 4 * l4 + t, c = l15;
+					const double w = x[t], pi = pv[t];
+					if(i < c) {          // R[i][c] = w / sqrt(p_i)
+						T[(j0 + i) + (j0 + c) * TS] = w * pi;
+						Dv[c + i * PT] = 0.0;   // Dinv[c][i], c > i: below the diagonal
+						Gd[i + c * PT] = 0.0;   // G[i][c], c > i
+					} else if(i == c) {
+						T[(j0 + i) + (j0 + i) * TS] = 1.0 / pi;
+						Dv[i + i * PT] = pi;
+						Gd[i + i * PT] = pi;
+						dinv[j0 + i] = pi;
+					} else {             // G[i][c] = w / sqrt(p_i), c < i  (= Dinv[c][i])
+						const double g = w * pi;
+						T[(j0 + i) + (j0 + c) * TS] = g;
+						Dv[c + i * PT] = g;
+						Gd[i + c * PT] = g;
+					}
+				}
+			}
 		}
-		if(i > j && i < n_valid) {
-			const double f = T[j + i * TS] / p; // R[j][i] / p_j (unscaled row j)
-			for(int c = cl; c < j; c += 8)
-				T[i + c * TS] -= f * T[j + c * TS];
-			if(cl == (j & 7))
-				T[i + j * TS] = -f;
-			for(int c = i + ((cl - i) & 7); c < ncol; c += 8)
-				T[i + c * TS] -= f * T[j + c * TS];
+		__syncthreads();
+		if(*fail)
+			return;
+		// ---- B: row panel. tiles t < J: G part (columns 16 t ..), tiles t >= J: R part (columns 16 (t + 1) ..)
+		if(wave < 7) {
+			const int ct = (wave < J) ? wave : wave + 1;
+			double *Y = T + j0 + (ct * 16) * TS;
+			const v4f64 x = tile_atb(Dv, 1, PT, Y, 1, TS, lane); // X[i][j] = sum_k Dinv[k][i] Y[k][j]
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+#pragma unroll
+			for(int r = 0; r < 4; ++ r)
+				Y[(l4 + 4 * r) + l15 * TS] = x[r];
+		} else if(lane < 16) { // wave 7: the carried right-hand side, y_J = Dinv^T y_J
+			double s = 0;
+			for(int k = 0; k < 16; ++ k)
+				s += Dv[k + lane * PT] * yv[j0 + k];
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			yv[j0 + lane] = s;
+		}
+		__syncthreads();
+		// ---- C: trailing update with the panel rows P = T[j0 .. j0 + 16, :]
+		{
+			const int nI = NB / 16 - 1 - J;         // row tiles I = J + 1 .. 7
+			const int nR = nI * (nI + 1) / 2;       // R part: I <= K
+			const int nG = nI * (J + 1);            // G part: Cb = 0 .. J
+			for(int q = wave; q < nR + nG; q += POTRF_THREADS / 64) {
+				int I, Ct;
+				bool gpart = q >= nR;
+				if(!gpart) {
+					// q -> (a <= b) in an nI x nI upper triangle, row-major over a
+					int a = 0, rem = q;
+					while(rem >= nI - a) {
+						rem -= nI - a;
+						++ a;
+					}
+					I = J + 1 + a;
+					Ct = I + rem;
+				} else {
+					const int g = q - nR;
+					I = J + 1 + g / (J + 1);
+					Ct = g % (J + 1);
+				}
+				const double *Pa = T + j0 + (I * 16) * TS;
+				v4f64 d;
+				if(gpart && Ct == J)
+					d = tile_atb(Pa, 1, TS, Gd, 1, PT, lane);
+				else
+					d = tile_atb(Pa, 1, TS, T + j0 + (Ct * 16) * TS, 1, TS, lane);
+				double *D = T + (I * 16) + (Ct * 16) * TS;
+				const bool assign = gpart && Ct == J; // first touch of this G tile
+#pragma unroll
+				for(int r = 0; r < 4; ++ r) {
+					double *dp = D + (l4 + 4 * r) + l15 * TS;
+					*dp = assign ? -d[r] : *dp - d[r];
+				}
+			}
+			if(tid < NB && tid >= j0 + 16) { // rhs: y_i -= sum_k P[k][i] y_J[k]
+				double s = 0;
+				for(int k = 0; k < 16; ++ k)
+					s += T[(j0 + k) + tid * TS] * yv[j0 + k];
+				yv[tid] -= s;
+			}
 		}
 		__syncthreads();
 	}
-	if(failed)
-		return;
-	if(tid < NB)
-		piv[tid] = (tid < n_valid) ? 1.0 / sqrt(T[tid + tid * TS]) : 1.0;
-	__syncthreads();
-	// scale: R[j][c] = T[j][c] * piv[j] (c >= j); G[i][c] = T[i][c] * piv[i] (c < i), G[i][i] = piv[i]
-	// write R (upper triangle + carried columns) back and the dense upper-triangular inverse
-	for(int e = tid; e < NB * NB; e += 1024) {
-		int r = e & (NB - 1), c = e >> 7;
-		if(r < n_valid && c >= r && c < ncol)
-			Ablk[r + (int64_t)c * ld] = (c == r) ? 1.0 / piv[r] : T[r + c * TS] * piv[r];
-		// tinv[r][c] (upper, r <= c) = G[c][r]
+	// ---- write back R (upper triangle), the carried rhs, and the dense upper-triangular inverse
+	for(int e = tid; e < NB * NB; e += POTRF_THREADS) {
+		const int r = e & (NB - 1), c = e >> 7;
+		if(r <= c && c != rhs_col)
+			Ablk[r + (int64_t)c * ld] = T[r + c * TS];
 		double v = 0;
 		if(r == c)
-			v = piv[r];
-		else if(r < c && c < n_valid)
-			v = T[c + r * TS] * piv[c];
+			v = dinv[r];
+		else if(r < c)
+			v = T[c + r * TS]; // G[c][r]
 		tinv[r + c * NB] = v;
 	}
+	if(rhs_col >= 0 && tid < n_valid)
+		Ablk[tid + (int64_t)rhs_col * ld] = yv[tid];
 }
 
 // backward substitution step for block column k (rows/cols k0 .. k0 + NB):
@@ -318,46 +491,79 @@ static void ensure_dense_work(spp_ctx *ctx, int64_t nblk)
 	ctx->dense.info.reserve(4);
 	ctx->dense.tinv_all.reserve((size_t)nblk * NB * NB);
 	ctx->dense.xtmp.reserve((size_t)(nblk + 1) * NB);
+	if(!ctx->dense.aux) {
+		int prio_lo = 0, prio_hi = 0; // the serial chain of the factorization preempts the bulk update
+		SPP_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+		SPP_HIP_CHECK(hipStreamCreateWithPriority(&ctx->dense.aux, hipStreamNonBlocking, prio_hi));
+		SPP_HIP_CHECK(hipEventCreateWithFlags(&ctx->dense.ev[0], hipEventDisableTiming));
+		SPP_HIP_CHECK(hipEventCreateWithFlags(&ctx->dense.ev[1], hipEventDisableTiming));
+	}
 	static bool attr_set = false;
 	if(!attr_set) {
 		SPP_HIP_CHECK(hipFuncSetAttribute((const void*)potrf_diag_kernel,
-			hipFuncAttributeMaxDynamicSharedMemorySize, (NB * TS + NB) * (int)sizeof(double)));
+			hipFuncAttributeMaxDynamicSharedMemorySize, POTRF_LDS_DOUBLES * (int)sizeof(double)));
 		attr_set = true;
 	}
 }
 
 // Factor the n_pad x n_pad matrix in d_A (ld = n_pad multiple of 128, n < n_pad real columns; column
-// n is carried along as right-hand side when has a padding column). Returns SPP_OK / SPP_NOT_POSDEF.
+// n is carried along as right-hand side). Returns SPP_OK / SPP_NOT_POSDEF.
+//
+// Schedule (lookahead over two streams): after the row panel k is solved, the trailing update is
+// split into (1) the tile row k+1 -- all the next diagonal block and the next row panel need -- and
+// (3) the rest. The serial chain potrf_diag(k+1) + trsm(k+1) runs on the auxiliary stream while (3)
+// keeps the whole chip busy on the main stream.
 int dense_potrf_upper(spp_ctx *ctx, double *d_A, int64_t n, int64_t ld, bool /*keep_inverses*/)
 {
 	SPP_REQUIRE(ld % NB == 0 && n < ld, SPP_E_BADARG, "dense_potrf_upper: ld must be a multiple of 128 and > n");
 	const int64_t nblk = (n + NB - 1) / NB;
 	ensure_dense_work(ctx, nblk);
-	hipStream_t s = ctx->stream;
+	hipStream_t s = ctx->stream, s2 = ctx->dense.aux;
+	hipEvent_t evA = ctx->dense.ev[0], evB = ctx->dense.ev[1];
 	hipLaunchKernelGGL(set_info_kernel, dim3(1), dim3(1), 0, s, ctx->dense.info.p);
 	const int64_t ncols = n + 1; // real columns + rhs column
-	for(int64_t k = 0; k < nblk; ++ k) {
+	auto potrf_and_panel = [&](hipStream_t st, int64_t k) {
 		const int64_t k0 = k * NB;
 		const int n_valid = (int)((n - k0 < NB) ? (n - k0) : NB);
 		double *tinv = ctx->dense.tinv_all.p + (size_t)k * NB * NB;
-		hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(1024), (NB * TS + NB) * sizeof(double), s,
+		hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(POTRF_THREADS), POTRF_LDS_DOUBLES * sizeof(double), st,
 			d_A + k0 + k0 * ld, ld, n_valid, (n_valid < NB) ? 1 : 0, tinv, ctx->dense.info.p, k0);
-		const int64_t c1 = k0 + NB; // first column right of the block
+		const int64_t c1 = k0 + NB;
+		if(c1 < ncols) // panel: R_kj = Tinv^T S_kj in place (A = tinv: 128 x 128; B = C = S[k0.., c1..])
+			launch_gemm<128, 32, 32, 32, 1>(st, NB, ncols - c1, NB, tinv, NB, d_A + k0 + c1 * ld, ld,
+				d_A + k0 + c1 * ld, ld, false);
+	};
+	potrf_and_panel(s, 0);
+	for(int64_t k = 0; k < nblk; ++ k) {
+		const int64_t k0 = k * NB, c1 = k0 + NB;
 		if(c1 >= ncols)
 			break;
-		const int64_t mrest = ncols - c1;
-		// panel: R_kj = Tinv^T S_kj, in place (A = tinv: K x M = 128 x 128; B = C = S[k0.., c1..])
-		launch_gemm<128, 32, 32, 32, 1>(s, NB, mrest, NB, tinv, NB, d_A + k0 + c1 * ld, ld,
-			d_A + k0 + c1 * ld, ld, false);
-		// trailing update: S[c1.., c1..] -= P^T P (upper tiles only), P = S[k0..k0+128, c1..]
-		const int64_t mrows = ((n < ld ? n : ld) - c1); // rows that matter: real rows only
-		if(mrows > 0) {
-			dom_begin(ctx);
-			dense_gemm_tn_sub(ctx, mrows, mrest, NB, d_A + k0 + c1 * ld, ld, d_A + k0 + c1 * ld, ld,
-				d_A + c1 + c1 * ld, ld, true);
-			// flops actually useful: upper triangle incl. rhs column
-			dom_end(ctx, 2.0 * NB * (0.5 * (double)mrows * (double)mrows + (double)mrows));
+		const int64_t mrest = ncols - c1;      // columns right of the block (incl. rhs)
+		const int64_t mrows = n - c1;          // real rows below the block
+		if(mrows <= 0)
+			break;
+		const double *P = d_A + k0 + c1 * ld;  // row panel k: 128 x mrest
+		// (1) tile row k+1: rows [c1, c1+128) x cols [c1, ncols)
+		const int64_t r1 = mrows < NB ? mrows : NB;
+		launch_gemm<128, 32, 32, 32, 0>(s, r1, mrest, NB, P, ld, P, ld, d_A + c1 + c1 * ld, ld, true);
+		const bool more = (k + 1 < nblk);
+		if(more) {
+			SPP_HIP_CHECK(hipEventRecord(evA, s));
+			SPP_HIP_CHECK(hipStreamWaitEvent(s2, evA, 0));
+			potrf_and_panel(s2, k + 1);
+			SPP_HIP_CHECK(hipEventRecord(evB, s2));
 		}
+		// (3) the rest: rows [c1+128, n) x cols [c1+128, ncols)
+		if(mrows > NB) {
+			const int64_t c2 = c1 + NB;
+			dom_begin(ctx);
+			dense_gemm_tn_sub(ctx, mrows - NB, mrest - NB, NB, P + NB * ld, ld, P + NB * ld, ld,
+				d_A + c2 + c2 * ld, ld, true);
+			const double mr = (double)(mrows - NB);
+			dom_end(ctx, 2.0 * NB * (0.5 * mr * mr + mr));
+		}
+		if(more)
+			SPP_HIP_CHECK(hipStreamWaitEvent(s, evB, 0));
 	}
 	SPP_HIP_CHECK(hipGetLastError());
 	int h_info = 0;

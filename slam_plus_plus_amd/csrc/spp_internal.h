@@ -119,6 +119,8 @@ struct DenseWork {
 	DevBuf<int> info;              // device flag: 0 ok, j+1 = pivot j non-positive
 	DevBuf<double> tinv_all;       // inverses of all diagonal blocks (nblk x NB x NB) kept for the solves
 	DevBuf<double> xtmp;           // solution of the backward substitution before it replaces y
+	hipStream_t aux = nullptr;     // lookahead stream: potrf_diag + trsm of the next panel
+	hipEvent_t ev[2] = {nullptr, nullptr};
 };
 
 // ------------------------------------------------------------------------------------------------

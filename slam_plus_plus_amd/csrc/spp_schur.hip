@@ -114,53 +114,89 @@ void obs_kernel(int64_t no, const int32_t *__restrict__ obs_lm, const int64_t *_
 		xw[a * DP + r] = Wl[r];
 }
 
-// ---- S block accumulation: one wave per work item, lane = output element --------------------------
+// ---- S block accumulation: one wave per work item -------------------------------------------------
+// Each LANE takes whole pairs (a, b) of the item's list (lane, lane + 64, ...): 2 x 9 independent
+// 16-byte loads fetch W_a and U_b, 108 FMAs form the DP x DP outer product sum W_a U_b^T in
+// registers. The 64 partial blocks are then summed IN LANE ORDER through LDS by DP*DP lanes, so for
+// lists of up to 64 pairs (the common case) the additions happen in exactly the order of the pair
+// list (= ascending landmark = the reference's order); longer lists add lane-strided partial sums.
+// No atomics: bit-reproducible.
+constexpr int SACC_WAVES = 2; // waves (items) per workgroup: 2 x 64 x (DP*DP+1) doubles of LDS
+
 template <int DP, int DL>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(SACC_WAVES * 64)
 void s_accum_kernel(int64_t n_items, const int32_t *__restrict__ item_blk, const int32_t *__restrict__ item_beg,
 	const int32_t *__restrict__ item_slot, const int32_t *__restrict__ sblk_i1, const int32_t *__restrict__ sblk_i2,
 	const int64_t *__restrict__ sblk_aoff, const int32_t *__restrict__ pair_a, const int32_t *__restrict__ pair_b,
 	const double *__restrict__ W, const double *__restrict__ Up, const double *__restrict__ vals,
 	int add_A, double *__restrict__ S, int64_t ld, double *__restrict__ partial)
 {
-	const int64_t item = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-	const int lane = threadIdx.x & 63;
-	if(item >= n_items || lane >= DP * DP)
-		return;
-	const int r = lane % DP, c = lane / DP;
+	constexpr int NE = DP * DP, BLK = DP * DL, RS = NE + 1;
+	__shared__ double red[SACC_WAVES][64 * RS];
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int64_t item = (int64_t)blockIdx.x * SACC_WAVES + wave;
+	if(item >= n_items)
+		return; // whole wave
 	const int32_t beg = item_beg[item], end = item_beg[item + 1];
-	double acc0 = 0, acc1 = 0;
-	int32_t q = beg;
-	for(; q + 1 < end; q += 2) { // two independent chains of loads in flight; summed in list order below
-		const double *w0 = W + (int64_t)pair_a[q] * DP * DL + r, *u0 = Up + (int64_t)pair_b[q] * DP * DL + c;
-		const double *w1 = W + (int64_t)pair_a[q + 1] * DP * DL + r, *u1 = Up + (int64_t)pair_b[q + 1] * DP * DL + c;
-		double s0 = 0, s1 = 0;
+	double acc[NE];
 #pragma unroll
-		for(int t = 0; t < DL; ++ t) {
-			s0 += w0[DP * t] * u0[DP * t];
-			s1 += w1[DP * t] * u1[DP * t];
+	for(int e = 0; e < NE; ++ e)
+		acc[e] = 0;
+	for(int32_t q = beg + lane; q < end; q += 64) {
+		const double *wp = W + (int64_t)pair_a[q] * BLK, *up = Up + (int64_t)pair_b[q] * BLK;
+		double w[BLK], u[BLK];
+		if((BLK & 1) == 0) {
+#pragma unroll
+			for(int e = 0; e < BLK; e += 2) {
+				const double2 tw = *(const double2*)(wp + e), tu = *(const double2*)(up + e);
+				w[e] = tw.x; w[e + 1] = tw.y;
+				u[e] = tu.x; u[e + 1] = tu.y;
+			}
+		} else {
+#pragma unroll
+			for(int e = 0; e < BLK; ++ e) {
+				w[e] = wp[e];
+				u[e] = up[e];
+			}
 		}
-		acc0 = (acc0 + s0) + s1; // left-to-right, the order of the pair list
-	}
-	if(q < end) {
-		const double *w0 = W + (int64_t)pair_a[q] * DP * DL + r, *u0 = Up + (int64_t)pair_b[q] * DP * DL + c;
-		double s0 = 0;
 #pragma unroll
-		for(int t = 0; t < DL; ++ t)
-			s0 += w0[DP * t] * u0[DP * t];
-		acc0 += s0;
+		for(int c = 0; c < DP; ++ c)
+#pragma unroll
+			for(int r = 0; r < DP; ++ r) {
+				double s = 0;
+#pragma unroll
+				for(int t = 0; t < DL; ++ t)
+					s += w[r + DP * t] * u[c + DP * t];
+				acc[r + DP * c] += s;
+			}
 	}
-	(void)acc1;
+	int nact = end - beg;
+	if(nact > 64)
+		nact = 64;
+	double *rw = red[wave];
+	if(lane < nact) {
+#pragma unroll
+		for(int e = 0; e < NE; ++ e)
+			rw[lane * RS + e] = acc[e];
+	}
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	if(lane >= NE)
+		return;
+	double sum = 0;
+	for(int l = 0; l < nact; ++ l)
+		sum += rw[l * RS + lane];
 	const int32_t b = item_blk[item];
 	const int32_t slot = item_slot[item];
 	if(slot >= 0) {
-		partial[(int64_t)slot * DP * DP + lane] = acc0;
+		partial[(int64_t)slot * NE + lane] = sum;
 		return;
 	}
 	const int64_t aoff = sblk_aoff[b];
 	if(add_A && aoff >= 0)
-		acc0 = vals[aoff + lane] + acc0; // AddTo_FBS: S = A + W V
-	S[((int64_t)sblk_i1[b] * DP + r) + ((int64_t)sblk_i2[b] * DP + c) * ld] = acc0;
+		sum = vals[aoff + lane] + sum; // AddTo_FBS: S = A + W V
+	const int r = lane % DP, c = lane / DP;
+	S[((int64_t)sblk_i1[b] * DP + r) + ((int64_t)sblk_i2[b] * DP + c) * ld] = sum;
 }
 
 // blocks whose pair list was split: sum the partial slots in order (+ A)
@@ -295,7 +331,7 @@ static void schur_form_t(spp_ctx *ctx, const double *d_vals, const double *d_rhs
 	phase_end(ctx, SPP_PHASE_SCHUR_INV);
 	phase_begin(ctx, SPP_PHASE_SCHUR_GEMM);
 	if(sp.n_items)
-		hipLaunchKernelGGL((s_accum_kernel<DP, DL>), dim3((unsigned)((sp.n_items + 3) / 4)), dim3(256), 0, s,
+		hipLaunchKernelGGL((s_accum_kernel<DP, DL>), dim3((unsigned)((sp.n_items + SACC_WAVES - 1) / SACC_WAVES)), dim3(SACC_WAVES * 64), 0, s,
 			sp.n_items, sp.item_blk.p, sp.item_beg.p, sp.item_slot.p, sp.sblk_i1.p, sp.sblk_i2.p, sp.sblk_aoff.p,
 			sp.pair_a.p, sp.pair_b.p, sp.W.p, sp.Up.p, d_vals, sp.add_A ? 1 : 0, S, ld, sp.partial.p);
 	if(sp.n_multi)
