@@ -307,3 +307,108 @@ class RefSolver:
             self.close()
         except Exception:
             pass
+
+
+# --------------------------------------------------------------------------------------------------
+# multi-GPU algebra: partial Schur complement of one landmark shard. Landmarks are dealt
+# round-robin over the ranks in ascending block-column order (the rule of build_schur_plan() in
+# slam_plus_plus_amd/csrc/spp_symbolic.cpp); rank 0 alone carries A and the pose part of eta.
+# --------------------------------------------------------------------------------------------------
+def landmark_shard(lam, rank, world):
+    dl = int(lam.dim.min())
+    lms = np.flatnonzero(lam.dim == dl)
+    return lms[np.arange(lms.size) % world == rank]
+
+
+def schur_partial(lam, eta, rank, world):
+    """Returns (S_partial (n_p x n_p, upper), x_partial (n_p), pose scalar index, shard landmark blocks)."""
+    L = lib()
+    dl = int(lam.dim.min())
+    poses = np.flatnonzero(lam.dim != dl)
+    mine = landmark_shard(lam, rank, world)
+    keep = np.concatenate([poses, mine]).astype(np.int64)
+    newid = -np.ones(lam.nb, dtype=np.int64)
+    newid[keep] = np.arange(keep.size)
+    sel = (newid[lam.row_idx] >= 0) & (newid[lam.col_idx] >= 0)
+    # sub-matrix in (poses | shard landmarks) order: guided order keeps relative ids, so a block
+    # (i, j) with i < j may flip when i is a landmark and j a pose
+    r, c = newid[lam.row_idx[sel]], newid[lam.col_idx[sel]]
+    tr = r > c
+    nr, nc_ = np.where(tr, c, r), np.where(tr, r, c)
+    sdim = lam.dim[keep]
+    st, blk, _ = structure_from_pairs(sdim, nr, nc_)
+    vals = np.zeros(st.nvals)
+    rows = lam.dim[lam.row_idx[sel]].astype(np.int32)
+    cols = lam.dim[lam.col_idx[sel]].astype(np.int32)
+    L.orc_permute_values(i64(int(sel.sum())), _p(np.ascontiguousarray(lam.blk_off[sel])),
+                         _p(np.ascontiguousarray(st.blk_off[blk])), _p(rows), _p(cols),
+                         _p(np.ascontiguousarray(tr, dtype=np.uint8)), _p(lam.vals), _p(vals))
+    sub = st.with_vals(vals)
+    idx = np.concatenate([np.arange(lam.base[b], lam.base[b + 1]) for b in keep])
+    x = np.ascontiguousarray(eta[idx])
+    n_p = int(sub.base[poses.size])
+    if rank != 0:  # A and the pose rhs belong to rank 0
+        for j in range(poses.size):
+            for p in range(sub.col_ptr[j], sub.col_ptr[j + 1]):
+                d = int(sub.dim[sub.row_idx[p]]) * int(sub.dim[j])
+                sub.vals[sub.blk_off[p]:sub.blk_off[p] + d] = 0
+        x[:n_p] = 0
+    S = np.zeros((n_p, n_p), order="F")
+    L.orc_schur_solve(i64(sub.nb), i64(poses.size), _p(sub.dim), _p(sub.base), _p(sub.col_ptr), _p(sub.row_idx),
+                      _p(sub.blk_off), _p(sub.vals), _p(x), _p(S))
+    # x[:n_p] now holds the partial reduced rhs if the (partial, possibly indefinite) LLT failed,
+    # or the solution of the partial system otherwise -> recompute it explicitly to be safe
+    xr = np.ascontiguousarray(eta[idx])
+    if rank != 0:
+        xr[:n_p] = 0
+    xred = xr[:n_p].copy()
+    for j in range(poses.size, sub.nb):
+        pe = sub.col_ptr[j + 1] - 1
+        C = sub.vals[sub.blk_off[pe]:sub.blk_off[pe] + dl * dl].reshape(dl, dl).T
+        Ci = np.empty(dl * dl)
+        if dl == 3:
+            L.orc_inverse3(_p(np.ascontiguousarray(C.T.ravel())), _p(Ci))
+            Cinv = Ci.reshape(3, 3).T
+        else:
+            Cinv = np.linalg.inv(C)
+        lj = xr[sub.base[j]:sub.base[j] + dl]
+        for p in range(sub.col_ptr[j], pe):
+            i = int(sub.row_idx[p])
+            di = int(sub.dim[i])
+            U = sub.vals[sub.blk_off[p]:sub.blk_off[p] + di * dl].reshape(dl, di).T
+            xred[sub.base[i]:sub.base[i] + di] += (U @ (-Cinv)) @ lj
+    pose_idx = np.concatenate([np.arange(lam.base[b], lam.base[b + 1]) for b in poses])
+    return S, xred, pose_idx, mine
+
+
+def schur_backsubstitute(lam, eta, dx_poses, blocks):
+    """dl = C^-1 (l - U^T dx) for the given landmark blocks (LinearSolver_Schur.h:1867-1881)"""
+    dl = int(lam.dim.min())
+    poses = np.flatnonzero(lam.dim != dl)
+    pbase = np.zeros(lam.nb, dtype=np.int64)
+    pbase[poses] = np.concatenate([[0], np.cumsum(lam.dim[poses])[:-1]])
+    out = {}
+    # blocks touching landmark b: column b (poses with smaller id) and row b in pose columns (larger id)
+    by_lm = {int(b): [] for b in blocks}
+    for p in range(lam.nnzb):
+        i, j = int(lam.row_idx[p]), int(lam.col_idx[p])
+        if i == j:
+            continue
+        if j in by_lm and lam.dim[i] != dl:
+            by_lm[j].append((i, p, False))
+        elif i in by_lm and lam.dim[j] != dl:
+            by_lm[i].append((j, p, True))
+    for b in blocks:
+        b = int(b)
+        pe = lam.col_ptr[b + 1] - 1
+        C = lam.vals[lam.blk_off[pe]:lam.blk_off[pe] + dl * dl].reshape(dl, dl).T
+        t = eta[lam.base[b]:lam.base[b] + dl].copy()
+        for (pose, p, transposed) in by_lm[b]:
+            dp = int(lam.dim[pose])
+            blk = lam.vals[lam.blk_off[p]:lam.blk_off[p] + dp * dl]
+            # U is dp x dl. Stored as is (column-major: element (r, q) at r + dp q), or transposed
+            # when the landmark id is smaller (dl x dp column-major: element (q, r) at q + dl r)
+            U = blk.reshape(dp, dl) if transposed else blk.reshape(dl, dp).T
+            t -= U.T @ dx_poses[pbase[pose]:pbase[pose] + dp]
+        out[b] = np.linalg.solve(C, t)
+    return out
