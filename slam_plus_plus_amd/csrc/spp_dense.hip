@@ -171,6 +171,107 @@ static void launch_gemm(hipStream_t s, int64_t M, int64_t N, int K, const double
 		M, N, K, A, lda, B, ldb, C, ldc, upper_only ? 1 : 0);
 }
 
+// --------------------------------------------------------------------------------------------------
+// Fully staged variant for the latency-critical chain kernels (row-panel solve and tile-row update):
+// K <= 128, both operand panels are loaded into LDS ONCE (all global loads in flight together, one
+// barrier), then the MFMAs run without further synchronization. LDS row stride K_MAX + 2 doubles:
+// conflict-free ds_read_b64 fragments (lanes l & 15 step 4 banks, lanes l >> 4 step 2 banks).
+// --------------------------------------------------------------------------------------------------
+constexpr int FS_KMAX = 128, FS_STRIDE = FS_KMAX + 2;
+
+template <int BM, int BN, int WM, int WN, int MODE>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64)
+void gemm_tn_staged_kernel(int64_t M, int64_t N, int K, const double *__restrict__ A, int64_t lda,
+	const double *B, int64_t ldb, double *C, int64_t ldc, int upper_only)
+{
+	constexpr int NWM = BM / WM, NWN = BN / WN, NT = NWM * NWN * 64;
+	constexpr int TA = WM / 16, TB = WN / 16;
+	extern __shared__ double fs_lds[];
+	double *As = fs_lds, *Bs = fs_lds + BM * FS_STRIDE;
+	const int64_t m0 = (int64_t)blockIdx.x * BM, n0 = (int64_t)blockIdx.y * BN;
+	if(upper_only && m0 >= n0 + BN)
+		return;
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int wm = (wave % NWM) * WM, wn = (wave / NWM) * WN;
+	const int l15 = lane & 15, l4 = lane >> 4;
+	const int kp = K >> 1; // 16-byte pieces per column
+	// stage A (BM columns) and B (BN columns): piece p -> (column p / kp, piece p % kp)
+	for(int p = tid; p < BM * kp; p += NT) {
+		const int col = p / kp, q = p - col * kp;
+		int64_t gc = m0 + col;
+		if(gc > M - 1) gc = M - 1;
+		*(double2*)(&As[col * FS_STRIDE + 2 * q]) = *(const double2*)(A + gc * lda + 2 * q);
+	}
+	for(int p = tid; p < BN * kp; p += NT) {
+		const int col = p / kp, q = p - col * kp;
+		int64_t gc = n0 + col;
+		if(gc > N - 1) gc = N - 1;
+		*(double2*)(&Bs[col * FS_STRIDE + 2 * q]) = *(const double2*)(B + gc * ldb + 2 * q);
+	}
+	v4f64 acc[TB][TA];
+#pragma unroll
+	for(int b = 0; b < TB; ++ b)
+#pragma unroll
+		for(int a = 0; a < TA; ++ a) {
+			acc[b][a] = (v4f64){0, 0, 0, 0};
+			if(MODE == 0) {
+				const int64_t m = m0 + wm + a * 16 + l15;
+#pragma unroll
+				for(int r = 0; r < 4; ++ r) {
+					const int64_t n = n0 + wn + b * 16 + l4 + 4 * r;
+					if(m < M && n < N)
+						acc[b][a][r] = -C[m + n * ldc];
+				}
+			}
+		}
+	__syncthreads();
+	for(int k4 = 0; k4 < K; k4 += 4) {
+		double fa[TA], fb[TB];
+#pragma unroll
+		for(int a = 0; a < TA; ++ a)
+			fa[a] = As[(wm + a * 16 + l15) * FS_STRIDE + k4 + l4];
+#pragma unroll
+		for(int b = 0; b < TB; ++ b)
+			fb[b] = Bs[(wn + b * 16 + l15) * FS_STRIDE + k4 + l4];
+#pragma unroll
+		for(int b = 0; b < TB; ++ b)
+#pragma unroll
+			for(int a = 0; a < TA; ++ a)
+				acc[b][a] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[b], fa[a], acc[b][a], 0, 0, 0);
+	}
+#pragma unroll
+	for(int b = 0; b < TB; ++ b)
+#pragma unroll
+		for(int a = 0; a < TA; ++ a) {
+			const int64_t m = m0 + wm + a * 16 + l15;
+#pragma unroll
+			for(int r = 0; r < 4; ++ r) {
+				const int64_t n = n0 + wn + b * 16 + l4 + 4 * r;
+				if(m < M && n < N)
+					C[m + n * ldc] = (MODE == 0) ? -acc[b][a][r] : acc[b][a][r];
+			}
+		}
+}
+
+template <int BM, int BN, int WM, int WN, int MODE>
+static void launch_gemm_staged(hipStream_t s, int64_t M, int64_t N, int K, const double *A, int64_t lda,
+	const double *B, int64_t ldb, double *C, int64_t ldc, bool upper_only)
+{
+	static bool attr = false;
+	const size_t lds = (size_t)(BM + BN) * FS_STRIDE * sizeof(double);
+	if(!attr) {
+		SPP_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tn_staged_kernel<BM, BN, WM, WN, MODE>,
+			hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		attr = true;
+	}
+	dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
+	dim3 block((BM / WM) * (BN / WN) * 64);
+	if(!grid.x || !grid.y)
+		return;
+	hipLaunchKernelGGL((gemm_tn_staged_kernel<BM, BN, WM, WN, MODE>), grid, block, lds, s,
+		M, N, K, A, lda, B, ldb, C, ldc, upper_only ? 1 : 0);
+}
+
 void dense_gemm_tn_sub(spp_ctx *ctx, int64_t m, int64_t n, int64_t k, const double *A, int64_t lda,
 	const double *B, int64_t ldb, double *C, int64_t ldc, bool upper_only)
 {
@@ -530,7 +631,7 @@ int dense_potrf_upper(spp_ctx *ctx, double *d_A, int64_t n, int64_t ld, bool /*k
 			d_A + k0 + k0 * ld, ld, n_valid, (n_valid < NB) ? 1 : 0, tinv, ctx->dense.info.p, k0);
 		const int64_t c1 = k0 + NB;
 		if(c1 < ncols) // panel: R_kj = Tinv^T S_kj in place (A = tinv: 128 x 128; B = C = S[k0.., c1..])
-			launch_gemm<128, 32, 32, 32, 1>(st, NB, ncols - c1, NB, tinv, NB, d_A + k0 + c1 * ld, ld,
+			launch_gemm_staged<128, 16, 32, 16, 1>(st, NB, ncols - c1, NB, tinv, NB, d_A + k0 + c1 * ld, ld,
 				d_A + k0 + c1 * ld, ld, false);
 	};
 	potrf_and_panel(s, 0);
@@ -545,7 +646,7 @@ int dense_potrf_upper(spp_ctx *ctx, double *d_A, int64_t n, int64_t ld, bool /*k
 		const double *P = d_A + k0 + c1 * ld;  // row panel k: 128 x mrest
 		// (1) tile row k+1: rows [c1, c1+128) x cols [c1, ncols)
 		const int64_t r1 = mrows < NB ? mrows : NB;
-		launch_gemm<128, 32, 32, 32, 0>(s, r1, mrest, NB, P, ld, P, ld, d_A + c1 + c1 * ld, ld, true);
+		launch_gemm_staged<64, 64, 32, 32, 0>(s, r1, mrest, NB, P, ld, P, ld, d_A + c1 + c1 * ld, ld, true);
 		const bool more = (k + 1 < nblk);
 		if(more) {
 			SPP_HIP_CHECK(hipEventRecord(evA, s));
