@@ -194,19 +194,36 @@ void gemm_tn_staged_kernel(int64_t M, int64_t N, int K, const double *__restrict
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int wm = (wave % NWM) * WM, wn = (wave / NWM) * WN;
 	const int l15 = lane & 15, l4 = lane >> 4;
-	const int kp = K >> 1; // 16-byte pieces per column
-	// stage A (BM columns) and B (BN columns): piece p -> (column p / kp, piece p % kp)
-	for(int p = tid; p < BM * kp; p += NT) {
-		const int col = p / kp, q = p - col * kp;
-		int64_t gc = m0 + col;
-		if(gc > M - 1) gc = M - 1;
-		*(double2*)(&As[col * FS_STRIDE + 2 * q]) = *(const double2*)(A + gc * lda + 2 * q);
-	}
-	for(int p = tid; p < BN * kp; p += NT) {
-		const int col = p / kp, q = p - col * kp;
-		int64_t gc = n0 + col;
-		if(gc > N - 1) gc = N - 1;
-		*(double2*)(&Bs[col * FS_STRIDE + 2 * q]) = *(const double2*)(B + gc * ldb + 2 * q);
+	// stage A (BM columns) and B (BN columns): piece p -> (column p / 64, piece p % 64); K == FS_KMAX.
+	// All loads of a thread are issued before its first LDS store (one exposed memory round trip).
+	constexpr int KP = FS_KMAX / 2, PA = (BM * KP) / NT, PB = (BN * KP) / NT;
+	static_assert((BM * KP) % NT == 0 && (BN * KP) % NT == 0, "staging must divide evenly");
+	{
+		double2 va[PA], vb[PB];
+#pragma unroll
+		for(int i = 0; i < PA; ++ i) {
+			const int p = tid + i * NT, col = p / KP, q = p % KP;
+			int64_t gc = m0 + col;
+			if(gc > M - 1) gc = M - 1;
+			va[i] = *(const double2*)(A + gc * lda + 2 * q);
+		}
+#pragma unroll
+		for(int i = 0; i < PB; ++ i) {
+			const int p = tid + i * NT, col = p / KP, q = p % KP;
+			int64_t gc = n0 + col;
+			if(gc > N - 1) gc = N - 1;
+			vb[i] = *(const double2*)(B + gc * ldb + 2 * q);
+		}
+#pragma unroll
+		for(int i = 0; i < PA; ++ i) {
+			const int p = tid + i * NT, col = p / KP, q = p % KP;
+			*(double2*)(&As[col * FS_STRIDE + 2 * q]) = va[i];
+		}
+#pragma unroll
+		for(int i = 0; i < PB; ++ i) {
+			const int p = tid + i * NT, col = p / KP, q = p % KP;
+			*(double2*)(&Bs[col * FS_STRIDE + 2 * q]) = vb[i];
+		}
 	}
 	v4f64 acc[TB][TA];
 #pragma unroll
@@ -225,7 +242,8 @@ void gemm_tn_staged_kernel(int64_t M, int64_t N, int K, const double *__restrict
 			}
 		}
 	__syncthreads();
-	for(int k4 = 0; k4 < K; k4 += 4) {
+#pragma unroll 4
+	for(int k4 = 0; k4 < FS_KMAX; k4 += 4) {
 		double fa[TA], fb[TB];
 #pragma unroll
 		for(int a = 0; a < TA; ++ a)
@@ -264,6 +282,7 @@ static void launch_gemm_staged(hipStream_t s, int64_t M, int64_t N, int K, const
 			hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 		attr = true;
 	}
+	SPP_REQUIRE(K == FS_KMAX, SPP_E_BADARG, "staged gemm: K must be 128");
 	dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
 	dim3 block((BM / WM) * (BN / WN) * 64);
 	if(!grid.x || !grid.y)
@@ -306,20 +325,32 @@ void dense_gemm_tn_sub(spp_ctx *ctx, int64_t m, int64_t n, int64_t k, const doub
 //        are exact identity; if has_rhs, column n_valid holds a right-hand side (rows < n_valid)
 //   out: upper triangle <- R_kk ; rhs column <- R_kk^-T rhs ;
 //        tinv (128 x 128 column-major, dense upper triangular) <- R_kk^-1
-// For each 16-wide panel J:
-//   A  (wave 0)   factor the 16 x 16 diagonal tile and invert it (square-root-free elimination whose
-//                 unused lower half accumulates (R_JJ^-1)^T, one wave, no workgroup barrier)
-//   B  (8 waves)  row panel: X = Dinv^T Y for the tiles right of the diagonal (R part) and left of it
-//                 (G part: the rows of (R^-1)^T accumulated in the unused LOWER triangle of the block)
-//   C  (8 waves)  trailing update T[I,K] -= P_I^T P_K (R part) and G[I,Cb] -= P_I^T G[J,Cb] (G part)
-// 3 workgroup barriers per panel instead of one per pivot.
+// Per 16-wide panel J (16 waves):
+//   B  row panel: X = Dinv^T Y for the tiles right of the diagonal (R part) and left of it (G part:
+//      the rows of (R^-1)^T accumulated in the unused LOWER triangle of the block); one tile per wave
+//   C  trailing update T[I,K] -= P_I^T P_K (R part), G[I,Cb] -= P_I^T G[J,Cb] (G part): waves 1..15
+//      take the tiles two at a time (independent MFMA chains); wave 0 updates the NEXT diagonal tile
+//      first and then
+//   A  factors and inverts that 16 x 16 tile in registers (square-root-free elimination, 5 double
+//      shuffles per pivot) while the other waves finish C -- the serial part hides under the update.
+// 2 workgroup barriers per panel. Dinv / G_JJ scratch tiles are double buffered (panel parity).
 // info[0] = first failing global pivot index + 1 (non-positive pivot, Eigen's LLT test).
 // --------------------------------------------------------------------------------------------------
 constexpr int NB = DENSE_NB;
 constexpr int TS = NB + 1;   // LDS column stride of the block image: element (r, c) at r + c * TS
 constexpr int PT = 17;       // column stride of the 16 x 16 scratch tiles
-constexpr int POTRF_THREADS = 512;
-constexpr int POTRF_LDS_DOUBLES = NB * TS + 3 * 16 * PT + 2 * NB + 8;
+constexpr int POTRF_THREADS = 1024;
+constexpr int POTRF_LDS_DOUBLES = NB * TS + 4 * 16 * PT + 2 * NB + 8;
+
+// wave-uniform broadcast of a double from a compile-time lane (two v_readlane_b32)
+__device__ __forceinline__ double readlane_f64(double v, int src_lane)
+{
+	union { double d; int i[2]; } u;
+	u.d = v;
+	u.i[0] = __builtin_amdgcn_readlane(u.i[0], src_lane);
+	u.i[1] = __builtin_amdgcn_readlane(u.i[1], src_lane);
+	return u.d;
+}
 
 // D (16 x 16) = sum_k A[k][i] * B[k][j], k = 0..15; A element (k, i) at a[k * aks + i * ais],
 // B element (k, j) at b[k * bks + j * bjs]. Result in the MFMA D layout (row (l>>4) + 4 r, col l & 15).
@@ -336,22 +367,114 @@ __device__ __forceinline__ v4f64 tile_atb(const double *a, int aks, int ais, con
 	return acc;
 }
 
+// two independent tiles at once: the loads and MFMA chains of both interleave
+__device__ __forceinline__ void tile_atb2(const double *a0, const double *b0, int b0ks, int b0js,
+	const double *a1, const double *b1, int b1ks, int b1js, int lane, v4f64 &d0, v4f64 &d1)
+{
+	d0 = (v4f64){0, 0, 0, 0};
+	d1 = (v4f64){0, 0, 0, 0};
+	const int l15 = lane & 15, l4 = lane >> 4;
+	double fa0[4], fb0[4], fa1[4], fb1[4];
+#pragma unroll
+	for(int kk = 0; kk < 4; ++ kk) {
+		fa0[kk] = a0[(kk * 4 + l4) + l15 * TS];
+		fb0[kk] = b0[(kk * 4 + l4) * b0ks + l15 * b0js];
+		fa1[kk] = a1[(kk * 4 + l4) + l15 * TS];
+		fb1[kk] = b1[(kk * 4 + l4) * b1ks + l15 * b1js];
+	}
+#pragma unroll
+	for(int kk = 0; kk < 4; ++ kk) {
+		d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa0[kk], fb0[kk], d0, 0, 0, 0);
+		d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa1[kk], fb1[kk], d1, 0, 0, 0);
+	}
+}
+
+// step A: factor + invert the 16 x 16 diagonal tile at (j0, j0) in registers (one wave).
+// Lane (c = l & 15, g = l >> 4) owns rows 4g..4g+3 of column c. The strictly lower half accumulates
+// G = (R_JJ^-1)^T:  pivot j, row i > j, f = W[j][i] / p_j:
+//     c < j : W[i][c] -= f W[j][c]   (G update)      c == j: W[i][j] = -f   (new G entry)
+//     c >= i: W[i][c] -= f W[j][c]   (trailing update)
+// Writes R (upper) and G (strictly lower) into T, Dinv / G_JJ into the scratch tiles, 1/R_jj into dinv.
+__device__ __forceinline__ void diag_tile_factor(double *T, double *Dv, double *Gd, double *dinv, int j0,
+	int lane, int *fail, int *info, int64_t k0)
+{
+	const int l15 = lane & 15, l4 = lane >> 4;
+	double x[4];
+#pragma unroll
+	for(int t = 0; t < 4; ++ t) {
+		const int i = 4 * l4 + t;
+		x[t] = (i <= l15) ? T[(j0 + i) + (j0 + l15) * TS] : 0.0;
+	}
+	bool bad = false;
+#pragma unroll
+	for(int j = 0; j < 16; ++ j) {
+		const int src = j | ((j >> 2) << 4); // lane holding W[j][j] in register j & 3 (compile-time)
+		const double p = readlane_f64(x[j & 3], src);
+		if(!(p > 0)) {
+			if(!bad && lane == 0) {
+				*fail = 1;
+				info[0] = (int)(k0 + j0 + j + 1);
+			}
+			bad = true;
+		}
+		double pinv = __builtin_amdgcn_rcp(p); // v_rcp_f64 + one Newton step
+		pinv = pinv * (2.0 - p * pinv);
+		const double rowj_c = __shfl(x[j & 3], l15 | ((j >> 2) << 4)); // W[j][c]
+#pragma unroll
+		for(int t = 0; t < 4; ++ t) {
+			const int i = 4 * l4 + t;
+			const double f = __shfl(x[j & 3], i | ((j >> 2) << 4)) * pinv; // W[j][i] / p
+			const bool below = i > j;
+			const double upd = x[t] - f * rowj_c;
+			x[t] = (below && l15 == j) ? -f : ((below && (l15 < j || l15 >= i)) ? upd : x[t]);
+		}
+	}
+	if(bad)
+		return;
+	double pv[4];
+#pragma unroll
+	for(int t = 0; t < 4; ++ t) {
+		const int i = 4 * l4 + t;
+		pv[t] = 1.0 / sqrt(__shfl(x[t], i | (l4 << 4))); // 1 / sqrt(W[i][i])
+	}
+#pragma unroll
+	for(int t = 0; t < 4; ++ t) {
+		const int i = 4 * l4 + t, c = l15;
+		const double w = x[t], pi = pv[t];
+		if(i < c) {          // R[i][c] = w / sqrt(p_i)
+			T[(j0 + i) + (j0 + c) * TS] = w * pi;
+			Dv[c + i * PT] = 0.0;   // Dinv[c][i], c > i: below the diagonal
+			Gd[i + c * PT] = 0.0;   // G[i][c], c > i
+		} else if(i == c) {
+			T[(j0 + i) + (j0 + i) * TS] = 1.0 / pi;
+			Dv[i + i * PT] = pi;
+			Gd[i + i * PT] = pi;
+			dinv[j0 + i] = pi;
+		} else {             // G[i][c] = w / sqrt(p_i), c < i  (= Dinv[c][i])
+			const double g = w * pi;
+			T[(j0 + i) + (j0 + c) * TS] = g;
+			Dv[c + i * PT] = g;
+			Gd[i + c * PT] = g;
+		}
+	}
+}
+
 __global__ __launch_bounds__(POTRF_THREADS)
 void potrf_diag_kernel(double *__restrict__ Ablk, int64_t ld, int n_valid, int has_rhs,
 	double *__restrict__ tinv, int *__restrict__ info, int64_t k0)
 {
 	extern __shared__ double sm[];
 	double *T = sm;                  // NB x NB image, stride TS
-	double *Dv = T + NB * TS;        // Dinv[k][i] at Dv[k + i * PT] (upper triangular, zeros below)
-	double *Gd = Dv + 16 * PT;       // G_JJ[r][c] = Dinv[c][r] at Gd[r + c * PT] (lower triangular incl. diagonal)
-	double *W = Gd + 16 * PT;        // work tile of step A
-	double *dinv = W + 16 * PT;      // 1 / R[j][j]
+	double *DvB = T + NB * TS;       // 2 x Dinv[k][i] at Dv[k + i * PT] (upper triangular, zeros below)
+	double *GdB = DvB + 2 * 16 * PT; // 2 x G_JJ[r][c] = Dinv[c][r] at Gd[r + c * PT] (lower triangular incl. diagonal)
+	double *dinv = GdB + 2 * 16 * PT; // 1 / R[j][j]
 	double *yv = dinv + NB;          // carried right-hand side
 	int *fail = (int*)(yv + NB);
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int l15 = lane & 15, l4 = lane >> 4;
+	constexpr int NW = POTRF_THREADS / 64;
 	{
-		// 16-byte loads, all 16 per thread in flight before the first LDS store
+		// 16-byte loads, all of a thread's loads in flight before its first LDS store
 		double2 v[NB * NB / 2 / POTRF_THREADS];
 #pragma unroll
 		for(int t = 0; t < NB * NB / 2 / POTRF_THREADS; ++ t) {
@@ -377,77 +500,15 @@ void potrf_diag_kernel(double *__restrict__ Ablk, int64_t ld, int n_valid, int h
 	if(rhs_col >= 0 && tid < NB)
 		T[tid + rhs_col * TS] = (tid == rhs_col) ? 1.0 : 0.0; // the rhs column becomes plain padding
 	__syncthreads();
+	if(wave == 0)
+		diag_tile_factor(T, DvB, GdB, dinv, 0, lane, fail, info, k0);
+	__syncthreads();
 
 	for(int J = 0; J < NB / 16; ++ J) {
-		const int j0 = J * 16;
-		// ---- A: diagonal tile, wave 0, in registers: lane (c = l & 15, g = l >> 4) owns rows 4g..4g+3 of
-		// column c. Square-root-free elimination; the strictly lower half accumulates G = (R_JJ^-1)^T:
-		//   pivot j, row i > j, f = W[j][i] / p_j:  c < j : W[i][c] -= f W[j][c]   (G update)
-		//                                           c == j: W[i][j]  = -f          (new G entry)
-		//                                           c >= i: W[i][c] -= f W[j][c]   (trailing update)
-		// Cross-lane traffic per pivot: 5 double shuffles + 1 uniform broadcast; no LDS round trips.
-		if(wave == 0) {
-			double x[4];
-#pragma unroll
-			for(int t = 0; t < 4; ++ t) {
-				const int i = 4 * l4 + t;
-				x[t] = (i <= l15) ? T[(j0 + i) + (j0 + l15) * TS] : 0.0;
-			}
-			bool bad = false;
-#pragma unroll
-			for(int j = 0; j < 16; ++ j) {
-				const int src = j | ((j >> 2) << 4); // lane holding W[j][j] in register j & 3
-				const double p = __shfl(x[j & 3], src);
-				if(!(p > 0)) {
-					if(!bad && lane == 0) {
-						*fail = 1;
-						info[0] = (int)(k0 + j0 + j + 1);
-					}
-					bad = true;
-				}
-				const double pinv = 1.0 / p;
-				const double rowj_c = __shfl(x[j & 3], l15 | ((j >> 2) << 4)); // W[j][c]
-#pragma unroll
-				for(int t = 0; t < 4; ++ t) {
-					const int i = 4 * l4 + t;
-					const double f = __shfl(x[j & 3], i | ((j >> 2) << 4)) * pinv; // W[j][i] / p
-					const bool below = i > j;
-					const double upd = x[t] - f * rowj_c;
-					x[t] = (below && l15 == j) ? -f : ((below && (l15 < j || l15 >= i)) ? upd : x[t]);
-				}
-			}
-			if(!bad) {
-				double pv[4];
-#pragma unroll
-				for(int t = 0; t < 4; ++ t) {
-					const int i = 4 * l4 + t;
-					pv[t] = 1.0 / sqrt(__shfl(x[t], i | (l4 << 4))); // 1 / sqrt(W[i][i])
-				}
-#pragma unroll
-				for(int t = 0; t < 4; ++ t) {
-					const int i = 4 * l4 + t, c = l15;
-					const double w = x[t], pi = pv[t];
-					if(i < c) {          // R[i][c] = w / sqrt(p_i)
-						T[(j0 + i) + (j0 + c) * TS] = w * pi;
-						Dv[c + i * PT] = 0.0;   // Dinv[c][i], c > i: below the diagonal
-						Gd[i + c * PT] = 0.0;   // G[i][c], c > i
-					} else if(i == c) {
-						T[(j0 + i) + (j0 + i) * TS] = 1.0 / pi;
-						Dv[i + i * PT] = pi;
-						Gd[i + i * PT] = pi;
-						dinv[j0 + i] = pi;
-					} else {             // G[i][c] = w / sqrt(p_i), c < i  (= Dinv[c][i])
-						const double g = w * pi;
-						T[(j0 + i) + (j0 + c) * TS] = g;
-						Dv[c + i * PT] = g;
-						Gd[i + c * PT] = g;
-					}
-				}
-			}
-		}
-		__syncthreads();
 		if(*fail)
 			return;
+		const int j0 = J * 16;
+		const double *Dv = DvB + (J & 1) * 16 * PT, *Gd = GdB + (J & 1) * 16 * PT;
 		// ---- B: row panel. tiles t < J: G part (columns 16 t ..), tiles t >= J: R part (columns 16 (t + 1) ..)
 		if(wave < 7) {
 			const int ct = (wave < J) ? wave : wave + 1;
@@ -458,7 +519,7 @@ void potrf_diag_kernel(double *__restrict__ Ablk, int64_t ld, int n_valid, int h
 #pragma unroll
 			for(int r = 0; r < 4; ++ r)
 				Y[(l4 + 4 * r) + l15 * TS] = x[r];
-		} else if(lane < 16) { // wave 7: the carried right-hand side, y_J = Dinv^T y_J
+		} else if(wave == 7 && lane < 16) { // the carried right-hand side, y_J = Dinv^T y_J
 			double s = 0;
 			for(int k = 0; k < 16; ++ k)
 				s += Dv[k + lane * PT] * yv[j0 + k];
@@ -467,16 +528,15 @@ void potrf_diag_kernel(double *__restrict__ Ablk, int64_t ld, int n_valid, int h
 			yv[j0 + lane] = s;
 		}
 		__syncthreads();
-		// ---- C: trailing update with the panel rows P = T[j0 .. j0 + 16, :]
+		// ---- C (+ A of the next panel on wave 0): trailing update with the panel rows P = T[j0 .. j0 + 16, :]
 		{
 			const int nI = NB / 16 - 1 - J;         // row tiles I = J + 1 .. 7
 			const int nR = nI * (nI + 1) / 2;       // R part: I <= K
 			const int nG = nI * (J + 1);            // G part: Cb = 0 .. J
-			for(int q = wave; q < nR + nG; q += POTRF_THREADS / 64) {
-				int I, Ct;
-				bool gpart = q >= nR;
+			// tile q -> (I, Ct, gpart); q = 0 is the next diagonal tile (I = K = J + 1)
+			auto decode = [&](int q, int &I, int &Ct, bool &gpart) {
+				gpart = q >= nR;
 				if(!gpart) {
-					// q -> (a <= b) in an nI x nI upper triangle, row-major over a
 					int a = 0, rem = q;
 					while(rem >= nI - a) {
 						rem -= nI - a;
@@ -489,29 +549,70 @@ void potrf_diag_kernel(double *__restrict__ Ablk, int64_t ld, int n_valid, int h
 					I = J + 1 + g / (J + 1);
 					Ct = g % (J + 1);
 				}
-				const double *Pa = T + j0 + (I * 16) * TS;
-				v4f64 d;
-				if(gpart && Ct == J)
-					d = tile_atb(Pa, 1, TS, Gd, 1, PT, lane);
-				else
-					d = tile_atb(Pa, 1, TS, T + j0 + (Ct * 16) * TS, 1, TS, lane);
-				double *D = T + (I * 16) + (Ct * 16) * TS;
-				const bool assign = gpart && Ct == J; // first touch of this G tile
+			};
+			if(wave == 0) {
+				if(nI > 0) {
+					const double *Pa = T + j0 + ((J + 1) * 16) * TS;
+					const v4f64 d = tile_atb(Pa, 1, TS, Pa, 1, TS, lane);
+					double *D = T + ((J + 1) * 16) + ((J + 1) * 16) * TS;
 #pragma unroll
-				for(int r = 0; r < 4; ++ r) {
-					double *dp = D + (l4 + 4 * r) + l15 * TS;
-					*dp = assign ? -d[r] : *dp - d[r];
+					for(int r = 0; r < 4; ++ r)
+						D[(l4 + 4 * r) + l15 * TS] -= d[r];
+					__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+					__builtin_amdgcn_wave_barrier();
+					diag_tile_factor(T, DvB + ((J + 1) & 1) * 16 * PT, GdB + ((J + 1) & 1) * 16 * PT, dinv,
+						j0 + 16, lane, fail, info, k0);
 				}
-			}
-			if(tid < NB && tid >= j0 + 16) { // rhs: y_i -= sum_k P[k][i] y_J[k]
-				double s = 0;
-				for(int k = 0; k < 16; ++ k)
-					s += T[(j0 + k) + tid * TS] * yv[j0 + k];
-				yv[tid] -= s;
+			} else {
+				for(int q = wave; q < nR + nG; q += 2 * (NW - 1)) { // q = 1 .. : waves 1..15, two tiles each round
+					const int q1 = q + (NW - 1);
+					int I0, C0, I1 = 0, C1 = 0;
+					bool g0, g1 = false;
+					decode(q, I0, C0, g0);
+					const bool have1 = q1 < nR + nG;
+					if(have1)
+						decode(q1, I1, C1, g1);
+					const double *a0 = T + j0 + (I0 * 16) * TS;
+					const bool gd0 = g0 && C0 == J;
+					const double *b0 = gd0 ? Gd : T + j0 + (C0 * 16) * TS;
+					if(have1) {
+						const double *a1 = T + j0 + (I1 * 16) * TS;
+						const bool gd1 = g1 && C1 == J;
+						const double *b1 = gd1 ? Gd : T + j0 + (C1 * 16) * TS;
+						v4f64 d0, d1;
+						tile_atb2(a0, b0, 1, gd0 ? PT : TS, a1, b1, 1, gd1 ? PT : TS, lane, d0, d1);
+						double *D0 = T + (I0 * 16) + (C0 * 16) * TS, *D1 = T + (I1 * 16) + (C1 * 16) * TS;
+#pragma unroll
+						for(int r = 0; r < 4; ++ r) {
+							double *dp = D0 + (l4 + 4 * r) + l15 * TS;
+							*dp = gd0 ? -d0[r] : *dp - d0[r]; // first touch of a G tile: assign
+							double *dq = D1 + (l4 + 4 * r) + l15 * TS;
+							*dq = gd1 ? -d1[r] : *dq - d1[r];
+						}
+					} else {
+						const v4f64 d0 = tile_atb(a0, 1, TS, b0, 1, gd0 ? PT : TS, lane);
+						double *D0 = T + (I0 * 16) + (C0 * 16) * TS;
+#pragma unroll
+						for(int r = 0; r < 4; ++ r) {
+							double *dp = D0 + (l4 + 4 * r) + l15 * TS;
+							*dp = gd0 ? -d0[r] : *dp - d0[r];
+						}
+					}
+				}
+				// rhs: y_i -= sum_k P[k][i] y_J[k], by the threads of waves 8..9
+				const int ti = tid - 512;
+				if(ti >= j0 + 16 && ti < NB) {
+					double s = 0;
+					for(int k = 0; k < 16; ++ k)
+						s += T[(j0 + k) + ti * TS] * yv[j0 + k];
+					yv[ti] -= s;
+				}
 			}
 		}
 		__syncthreads();
 	}
+	if(*fail)
+		return;
 	// ---- write back R (upper triangle), the carried rhs, and the dense upper-triangular inverse
 	for(int e = tid; e < NB * NB; e += POTRF_THREADS) {
 		const int r = e & (NB - 1), c = e >> 7;
@@ -635,6 +736,7 @@ int dense_potrf_upper(spp_ctx *ctx, double *d_A, int64_t n, int64_t ld, bool /*k
 				d_A + k0 + c1 * ld, ld, false);
 	};
 	potrf_and_panel(s, 0);
+	bool bulk_pending = false;
 	for(int64_t k = 0; k < nblk; ++ k) {
 		const int64_t k0 = k * NB, c1 = k0 + NB;
 		if(c1 >= ncols)
@@ -644,28 +746,38 @@ int dense_potrf_upper(spp_ctx *ctx, double *d_A, int64_t n, int64_t ld, bool /*k
 		if(mrows <= 0)
 			break;
 		const double *P = d_A + k0 + c1 * ld;  // row panel k: 128 x mrest
-		// (1) tile row k+1: rows [c1, c1+128) x cols [c1, ncols)
+		// the bulk update of step k-1 touched everything below/right of tile row k: it must be
+		// complete before tile row k+1 is updated again
+		if(bulk_pending) {
+			SPP_HIP_CHECK(hipStreamWaitEvent(s, evB, 0));
+			bulk_pending = false;
+		}
+		if(mrows > NB)
+			SPP_HIP_CHECK(hipEventRecord(evA, s)); // row panel k is complete at this point of the chain
+		// (1) tile row k+1: rows [c1, c1+128) x cols [c1, ncols)   -- chain stream
 		const int64_t r1 = mrows < NB ? mrows : NB;
 		launch_gemm_staged<64, 64, 32, 32, 0>(s, r1, mrest, NB, P, ld, P, ld, d_A + c1 + c1 * ld, ld, true);
-		const bool more = (k + 1 < nblk);
-		if(more) {
-			SPP_HIP_CHECK(hipEventRecord(evA, s));
-			SPP_HIP_CHECK(hipStreamWaitEvent(s2, evA, 0));
-			potrf_and_panel(s2, k + 1);
-			SPP_HIP_CHECK(hipEventRecord(evB, s2));
-		}
-		// (3) the rest: rows [c1+128, n) x cols [c1+128, ncols)
+		// (2) the rest: rows [c1+128, n) x cols [c1+128, ncols)     -- bulk stream, needs panel k only
 		if(mrows > NB) {
 			const int64_t c2 = c1 + NB;
+			SPP_HIP_CHECK(hipStreamWaitEvent(s2, evA, 0));
+			hipStream_t keep = ctx->stream;
+			ctx->stream = s2; // dom events + gemm launch on the bulk stream
 			dom_begin(ctx);
 			dense_gemm_tn_sub(ctx, mrows - NB, mrest - NB, NB, P + NB * ld, ld, P + NB * ld, ld,
 				d_A + c2 + c2 * ld, ld, true);
 			const double mr = (double)(mrows - NB);
 			dom_end(ctx, 2.0 * NB * (0.5 * mr * mr + mr));
+			ctx->stream = keep;
+			SPP_HIP_CHECK(hipEventRecord(evB, s2));
+			bulk_pending = true;
 		}
-		if(more)
-			SPP_HIP_CHECK(hipStreamWaitEvent(s, evB, 0));
+		// (3) next diagonal block + row panel                        -- chain stream, overlaps (2)
+		if(k + 1 < nblk)
+			potrf_and_panel(s, k + 1);
 	}
+	if(bulk_pending)
+		SPP_HIP_CHECK(hipStreamWaitEvent(s, evB, 0));
 	SPP_HIP_CHECK(hipGetLastError());
 	int h_info = 0;
 	SPP_HIP_CHECK(hipMemcpyAsync(&h_info, ctx->dense.info.p, sizeof(int), hipMemcpyDeviceToHost, s));
