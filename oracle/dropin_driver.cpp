@@ -112,5 +112,5 @@ int main(int n_arg_num, const char **p_arg_list)
 	}
 	printf("poses %lu edges %lu max_abs_diff %.3e max_abs_state %.3e\n", (unsigned long)n_poses,
 		(unsigned long)edges.size(), f_max, f_norm);
-	return (f_max <= 1e-7 * std::max(1.0, f_norm))? 0 : 1;
+	return (f_max <= 1e-6 * std::max(1.0, f_norm))? 0 : 1;
 }

@@ -28,11 +28,11 @@
 // CONSECUTIVE ROWS of C: every store/load of C touches whole 128-byte segments of a column.
 
 #include "spp_internal.h"
+#include "spp_tiles.h"
 #include <stdlib.h>
 
 namespace spp {
 
-typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 16;           // k-slab staged through LDS
 constexpr int LDS_STRIDE = 18;   // doubles per tile column in LDS: conflict-free ds_read_b64, 16-B aligned
@@ -338,126 +338,8 @@ void dense_gemm_tn_sub(spp_ctx *ctx, int64_t m, int64_t n, int64_t k, const doub
 // --------------------------------------------------------------------------------------------------
 constexpr int NB = DENSE_NB;
 constexpr int TS = NB + 1;   // LDS column stride of the block image: element (r, c) at r + c * TS
-constexpr int PT = 17;       // column stride of the 16 x 16 scratch tiles
 constexpr int POTRF_THREADS = 1024;
 constexpr int POTRF_LDS_DOUBLES = NB * TS + 4 * 16 * PT + 2 * NB + 8;
-
-// wave-uniform broadcast of a double from a compile-time lane (two v_readlane_b32)
-__device__ __forceinline__ double readlane_f64(double v, int src_lane)
-{
-	union { double d; int i[2]; } u;
-	u.d = v;
-	u.i[0] = __builtin_amdgcn_readlane(u.i[0], src_lane);
-	u.i[1] = __builtin_amdgcn_readlane(u.i[1], src_lane);
-	return u.d;
-}
-
-// D (16 x 16) = sum_k A[k][i] * B[k][j], k = 0..15; A element (k, i) at a[k * aks + i * ais],
-// B element (k, j) at b[k * bks + j * bjs]. Result in the MFMA D layout (row (l>>4) + 4 r, col l & 15).
-__device__ __forceinline__ v4f64 tile_atb(const double *a, int aks, int ais, const double *b, int bks, int bjs, int lane)
-{
-	v4f64 acc = (v4f64){0, 0, 0, 0};
-	const int l15 = lane & 15, l4 = lane >> 4;
-#pragma unroll
-	for(int kk = 0; kk < 4; ++ kk) {
-		const double fa = a[(kk * 4 + l4) * aks + l15 * ais];
-		const double fb = b[(kk * 4 + l4) * bks + l15 * bjs];
-		acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, fb, acc, 0, 0, 0);
-	}
-	return acc;
-}
-
-// two independent tiles at once: the loads and MFMA chains of both interleave
-__device__ __forceinline__ void tile_atb2(const double *a0, const double *b0, int b0ks, int b0js,
-	const double *a1, const double *b1, int b1ks, int b1js, int lane, v4f64 &d0, v4f64 &d1)
-{
-	d0 = (v4f64){0, 0, 0, 0};
-	d1 = (v4f64){0, 0, 0, 0};
-	const int l15 = lane & 15, l4 = lane >> 4;
-	double fa0[4], fb0[4], fa1[4], fb1[4];
-#pragma unroll
-	for(int kk = 0; kk < 4; ++ kk) {
-		fa0[kk] = a0[(kk * 4 + l4) + l15 * TS];
-		fb0[kk] = b0[(kk * 4 + l4) * b0ks + l15 * b0js];
-		fa1[kk] = a1[(kk * 4 + l4) + l15 * TS];
-		fb1[kk] = b1[(kk * 4 + l4) * b1ks + l15 * b1js];
-	}
-#pragma unroll
-	for(int kk = 0; kk < 4; ++ kk) {
-		d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa0[kk], fb0[kk], d0, 0, 0, 0);
-		d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa1[kk], fb1[kk], d1, 0, 0, 0);
-	}
-}
-
-// step A: factor + invert the 16 x 16 diagonal tile at (j0, j0) in registers (one wave).
-// Lane (c = l & 15, g = l >> 4) owns rows 4g..4g+3 of column c. The strictly lower half accumulates
-// G = (R_JJ^-1)^T:  pivot j, row i > j, f = W[j][i] / p_j:
-//     c < j : W[i][c] -= f W[j][c]   (G update)      c == j: W[i][j] = -f   (new G entry)
-//     c >= i: W[i][c] -= f W[j][c]   (trailing update)
-// Writes R (upper) and G (strictly lower) into T, Dinv / G_JJ into the scratch tiles, 1/R_jj into dinv.
-__device__ __forceinline__ void diag_tile_factor(double *T, double *Dv, double *Gd, double *dinv, int j0,
-	int lane, int *fail, int *info, int64_t k0)
-{
-	const int l15 = lane & 15, l4 = lane >> 4;
-	double x[4];
-#pragma unroll
-	for(int t = 0; t < 4; ++ t) {
-		const int i = 4 * l4 + t;
-		x[t] = (i <= l15) ? T[(j0 + i) + (j0 + l15) * TS] : 0.0;
-	}
-	bool bad = false;
-#pragma unroll
-	for(int j = 0; j < 16; ++ j) {
-		const int src = j | ((j >> 2) << 4); // lane holding W[j][j] in register j & 3 (compile-time)
-		const double p = readlane_f64(x[j & 3], src);
-		if(!(p > 0)) {
-			if(!bad && lane == 0) {
-				*fail = 1;
-				info[0] = (int)(k0 + j0 + j + 1);
-			}
-			bad = true;
-		}
-		double pinv = __builtin_amdgcn_rcp(p); // v_rcp_f64 + one Newton step
-		pinv = pinv * (2.0 - p * pinv);
-		const double rowj_c = __shfl(x[j & 3], l15 | ((j >> 2) << 4)); // W[j][c]
-#pragma unroll
-		for(int t = 0; t < 4; ++ t) {
-			const int i = 4 * l4 + t;
-			const double f = __shfl(x[j & 3], i | ((j >> 2) << 4)) * pinv; // W[j][i] / p
-			const bool below = i > j;
-			const double upd = x[t] - f * rowj_c;
-			x[t] = (below && l15 == j) ? -f : ((below && (l15 < j || l15 >= i)) ? upd : x[t]);
-		}
-	}
-	if(bad)
-		return;
-	double pv[4];
-#pragma unroll
-	for(int t = 0; t < 4; ++ t) {
-		const int i = 4 * l4 + t;
-		pv[t] = 1.0 / sqrt(__shfl(x[t], i | (l4 << 4))); // 1 / sqrt(W[i][i])
-	}
-#pragma unroll
-	for(int t = 0; t < 4; ++ t) {
-		const int i = 4 * l4 + t, c = l15;
-		const double w = x[t], pi = pv[t];
-		if(i < c) {          // R[i][c] = w / sqrt(p_i)
-			T[(j0 + i) + (j0 + c) * TS] = w * pi;
-			Dv[c + i * PT] = 0.0;   // Dinv[c][i], c > i: below the diagonal
-			Gd[i + c * PT] = 0.0;   // G[i][c], c > i
-		} else if(i == c) {
-			T[(j0 + i) + (j0 + i) * TS] = 1.0 / pi;
-			Dv[i + i * PT] = pi;
-			Gd[i + i * PT] = pi;
-			dinv[j0 + i] = pi;
-		} else {             // G[i][c] = w / sqrt(p_i), c < i  (= Dinv[c][i])
-			const double g = w * pi;
-			T[(j0 + i) + (j0 + c) * TS] = g;
-			Dv[c + i * PT] = g;
-			Gd[i + c * PT] = g;
-		}
-	}
-}
 
 __global__ __launch_bounds__(POTRF_THREADS)
 void potrf_diag_kernel(double *__restrict__ Ablk, int64_t ld, int n_valid, int has_rhs,
@@ -501,7 +383,7 @@ void potrf_diag_kernel(double *__restrict__ Ablk, int64_t ld, int n_valid, int h
 		T[tid + rhs_col * TS] = (tid == rhs_col) ? 1.0 : 0.0; // the rhs column becomes plain padding
 	__syncthreads();
 	if(wave == 0)
-		diag_tile_factor(T, DvB, GdB, dinv, 0, lane, fail, info, k0);
+		diag_tile_factor<TS>(T, DvB, GdB, dinv, 0, lane, fail, info, k0);
 	__syncthreads();
 
 	for(int J = 0; J < NB / 16; ++ J) {
@@ -560,7 +442,7 @@ void potrf_diag_kernel(double *__restrict__ Ablk, int64_t ld, int n_valid, int h
 						D[(l4 + 4 * r) + l15 * TS] -= d[r];
 					__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 					__builtin_amdgcn_wave_barrier();
-					diag_tile_factor(T, DvB + ((J + 1) & 1) * 16 * PT, GdB + ((J + 1) & 1) * 16 * PT, dinv,
+					diag_tile_factor<TS>(T, DvB + ((J + 1) & 1) * 16 * PT, GdB + ((J + 1) & 1) * 16 * PT, dinv,
 						j0 + 16, lane, fail, info, k0);
 				}
 			} else {
@@ -580,7 +462,7 @@ void potrf_diag_kernel(double *__restrict__ Ablk, int64_t ld, int n_valid, int h
 						const bool gd1 = g1 && C1 == J;
 						const double *b1 = gd1 ? Gd : T + j0 + (C1 * 16) * TS;
 						v4f64 d0, d1;
-						tile_atb2(a0, b0, 1, gd0 ? PT : TS, a1, b1, 1, gd1 ? PT : TS, lane, d0, d1);
+						tile_atb2<TS>(a0, b0, 1, gd0 ? PT : TS, a1, b1, 1, gd1 ? PT : TS, lane, d0, d1);
 						double *D0 = T + (I0 * 16) + (C0 * 16) * TS, *D1 = T + (I1 * 16) + (C1 * 16) * TS;
 #pragma unroll
 						for(int r = 0; r < 4; ++ r) {
@@ -641,11 +523,19 @@ void trsv_back_kernel(const double *__restrict__ R, int64_t ld, int64_t k0, int 
 	__shared__ double part[2][NB];
 	const int tid = threadIdx.x;
 	{
+		// two threads per row, 64 columns each; 8 independent partial sums keep 8 loads in flight
 		const int r = tid & (NB - 1), h = tid >> 7;
-		double s = 0;
-		for(int c = h * 64; c < h * 64 + 64; ++ c)
-			if(c < nv) s += tinv[r + c * NB] * y[k0 + c];
-		part[h][r] = s;
+		double s8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+		for(int c8 = 0; c8 < 64; c8 += 8) {
+#pragma unroll
+			for(int u = 0; u < 8; ++ u) {
+				const int c = h * 64 + c8 + u;
+				const double t = tinv[r + c * NB], yy = y[k0 + c];
+				s8[u] += (c < nv) ? t * yy : 0.0;
+			}
+		}
+		part[h][r] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
 	}
 	__syncthreads();
 	if(tid < NB)
@@ -658,10 +548,23 @@ void trsv_back_kernel(const double *__restrict__ R, int64_t ld, int64_t k0, int 
 	const int64_t i = (int64_t)(blockIdx.x - 1) * 256 + tid;
 	if(i < k0) {
 		const double *row = R + i + k0 * ld;
+		// real columns only (the padding of the last block holds the rhs column); 16 loads in flight
+		double s16[16];
+#pragma unroll
+		for(int u = 0; u < 16; ++ u)
+			s16[u] = 0;
+		int c = 0;
+		for(; c + 16 <= nv; c += 16) {
+#pragma unroll
+			for(int u = 0; u < 16; ++ u)
+				s16[u] += row[(int64_t)(c + u) * ld] * xk[c + u];
+		}
+		for(; c < nv; ++ c)
+			s16[0] += row[(int64_t)c * ld] * xk[c];
 		double s = 0;
-#pragma unroll 8
-		for(int c = 0; c < nv; ++ c) // real columns only: the padding of the last block holds the rhs column
-			s += row[(int64_t)c * ld] * xk[c];
+#pragma unroll
+		for(int u = 0; u < 16; ++ u)
+			s += s16[u];
 		y[i] -= s;
 	}
 }
@@ -715,21 +618,25 @@ static void ensure_dense_work(spp_ctx *ctx, int64_t nblk)
 // split into (1) the tile row k+1 -- all the next diagonal block and the next row panel need -- and
 // (3) the rest. The serial chain potrf_diag(k+1) + trsm(k+1) runs on the auxiliary stream while (3)
 // keeps the whole chip busy on the main stream.
-int dense_potrf_upper(spp_ctx *ctx, double *d_A, int64_t n, int64_t ld, bool /*keep_inverses*/)
+// Generic driver: eliminates `nsteps` diagonal blocks of the matrix in d_A.
+//   n      number of pivot scalars (the last block may be partial: n_valid = n - k0 < 128, padding rows
+//          must then be exact identity and, if has_rhs, column n carries a right-hand side)
+//   rows   extent of the trailing region that receives updates (n for a full factorization, the
+//          padded front height for a partial front factorization)
+//   ncols  columns carried along (rows + 1 with a rhs column)
+// Does not synchronize; failures are recorded in ctx->dense.info (first failing pivot + 1).
+void dense_factor_steps(spp_ctx *ctx, double *d_A, int64_t ld, int64_t n, int64_t rows, int64_t ncols,
+	int64_t nsteps, bool has_rhs)
 {
-	SPP_REQUIRE(ld % NB == 0 && n < ld, SPP_E_BADARG, "dense_potrf_upper: ld must be a multiple of 128 and > n");
-	const int64_t nblk = (n + NB - 1) / NB;
-	ensure_dense_work(ctx, nblk);
+	ensure_dense_work(ctx, nsteps);
 	hipStream_t s = ctx->stream, s2 = ctx->dense.aux;
 	hipEvent_t evA = ctx->dense.ev[0], evB = ctx->dense.ev[1];
-	hipLaunchKernelGGL(set_info_kernel, dim3(1), dim3(1), 0, s, ctx->dense.info.p);
-	const int64_t ncols = n + 1; // real columns + rhs column
 	auto potrf_and_panel = [&](hipStream_t st, int64_t k) {
 		const int64_t k0 = k * NB;
 		const int n_valid = (int)((n - k0 < NB) ? (n - k0) : NB);
 		double *tinv = ctx->dense.tinv_all.p + (size_t)k * NB * NB;
 		hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(POTRF_THREADS), POTRF_LDS_DOUBLES * sizeof(double), st,
-			d_A + k0 + k0 * ld, ld, n_valid, (n_valid < NB) ? 1 : 0, tinv, ctx->dense.info.p, k0);
+			d_A + k0 + k0 * ld, ld, n_valid, (has_rhs && n_valid < NB) ? 1 : 0, tinv, ctx->dense.info.p, k0);
 		const int64_t c1 = k0 + NB;
 		if(c1 < ncols) // panel: R_kj = Tinv^T S_kj in place (A = tinv: 128 x 128; B = C = S[k0.., c1..])
 			launch_gemm_staged<128, 16, 32, 16, 1>(st, NB, ncols - c1, NB, tinv, NB, d_A + k0 + c1 * ld, ld,
@@ -737,12 +644,12 @@ int dense_potrf_upper(spp_ctx *ctx, double *d_A, int64_t n, int64_t ld, bool /*k
 	};
 	potrf_and_panel(s, 0);
 	bool bulk_pending = false;
-	for(int64_t k = 0; k < nblk; ++ k) {
+	for(int64_t k = 0; k < nsteps; ++ k) {
 		const int64_t k0 = k * NB, c1 = k0 + NB;
 		if(c1 >= ncols)
 			break;
 		const int64_t mrest = ncols - c1;      // columns right of the block (incl. rhs)
-		const int64_t mrows = n - c1;          // real rows below the block
+		const int64_t mrows = rows - c1;       // rows below the block that receive updates
 		if(mrows <= 0)
 			break;
 		const double *P = d_A + k0 + c1 * ld;  // row panel k: 128 x mrest
@@ -757,7 +664,7 @@ int dense_potrf_upper(spp_ctx *ctx, double *d_A, int64_t n, int64_t ld, bool /*k
 		// (1) tile row k+1: rows [c1, c1+128) x cols [c1, ncols)   -- chain stream
 		const int64_t r1 = mrows < NB ? mrows : NB;
 		launch_gemm_staged<64, 64, 32, 32, 0>(s, r1, mrest, NB, P, ld, P, ld, d_A + c1 + c1 * ld, ld, true);
-		// (2) the rest: rows [c1+128, n) x cols [c1+128, ncols)     -- bulk stream, needs panel k only
+		// (2) the rest: rows [c1+128, rows) x cols [c1+128, ncols)  -- bulk stream, needs panel k only
 		if(mrows > NB) {
 			const int64_t c2 = c1 + NB;
 			SPP_HIP_CHECK(hipStreamWaitEvent(s2, evA, 0));
@@ -773,16 +680,39 @@ int dense_potrf_upper(spp_ctx *ctx, double *d_A, int64_t n, int64_t ld, bool /*k
 			bulk_pending = true;
 		}
 		// (3) next diagonal block + row panel                        -- chain stream, overlaps (2)
-		if(k + 1 < nblk)
+		if(k + 1 < nsteps)
 			potrf_and_panel(s, k + 1);
 	}
 	if(bulk_pending)
 		SPP_HIP_CHECK(hipStreamWaitEvent(s, evB, 0));
 	SPP_HIP_CHECK(hipGetLastError());
+}
+
+void dense_reserve(spp_ctx *ctx, int64_t nblk)
+{
+	ensure_dense_work(ctx, nblk);
+}
+
+void dense_info_reset(spp_ctx *ctx)
+{
+	ctx->dense.info.reserve(4);
+	hipLaunchKernelGGL(set_info_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->dense.info.p);
+}
+
+int dense_info_fetch(spp_ctx *ctx)
+{
 	int h_info = 0;
-	SPP_HIP_CHECK(hipMemcpyAsync(&h_info, ctx->dense.info.p, sizeof(int), hipMemcpyDeviceToHost, s));
-	SPP_HIP_CHECK(hipStreamSynchronize(s));
-	return h_info ? SPP_NOT_POSDEF : SPP_OK;
+	SPP_HIP_CHECK(hipMemcpyAsync(&h_info, ctx->dense.info.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+	SPP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	return h_info;
+}
+
+int dense_potrf_upper(spp_ctx *ctx, double *d_A, int64_t n, int64_t ld, bool /*keep_inverses*/)
+{
+	SPP_REQUIRE(ld % NB == 0 && n < ld, SPP_E_BADARG, "dense_potrf_upper: ld must be a multiple of 128 and > n");
+	dense_info_reset(ctx);
+	dense_factor_steps(ctx, d_A, ld, n, n, n + 1, (n + NB - 1) / NB, true);
+	return dense_info_fetch(ctx) ? SPP_NOT_POSDEF : SPP_OK;
 }
 
 // back substitution R x = y with y in d_b (n entries); uses the block inverses of the last potrf.

@@ -25,8 +25,11 @@
 // graphs"); only the large fronts near the root reach the MFMA path.
 
 #include "spp_internal.h"
+#include "spp_tiles.h"
 #include <algorithm>
 #include <numeric>
+#include <stdio.h>
+#include <stdlib.h>
 
 namespace spp {
 
@@ -39,11 +42,14 @@ struct SparsePlan {
 	std::vector<int32_t> h_front_h, h_front_w; // per supernode (scalar sizes)
 	std::vector<int64_t> h_front_off;
 	std::vector<int32_t> h_level_fronts;
-	std::vector<int32_t> h_big;                // supernodes routed through the dense kernels
+	std::vector<int32_t> h_front_ld, h_front_pad, h_front_cls;
+	std::vector<int32_t> h_cls_ptr;            // [n_levels * 4 + 1]: fronts of (level, class) in level_fronts
+	std::vector<int32_t> h_child_ptr, h_child_list, h_asm_ptr;
 	// device
 	DevBuf<int32_t> level_fronts;              // fronts grouped by level
 	DevBuf<int64_t> front_off;                 // [ns] offset of F in `fronts`
 	DevBuf<int32_t> front_h, front_w, front_ld; // [ns]
+	DevBuf<int32_t> front_pad;                 // [ns] identity padding inserted after the pivot block (big fronts)
 	DevBuf<int64_t> front_voff;                // [ns] offset of the solve work vector
 	DevBuf<int32_t> asm_ptr;                   // [ns+1]
 	DevBuf<int64_t> asm_src;                   // [n_asm] (offset in vals << 1) | transpose
@@ -332,7 +338,7 @@ void sparse_analyze(spp_ctx *ctx)
 	}
 
 	// ---- 6. flat arrays
-	std::vector<int32_t> front_h(ns), front_w(ns), front_ld(ns), rows_ptr(ns + 1, 0), rows;
+	std::vector<int32_t> front_h(ns), front_w(ns), front_ld(ns), front_pad(ns), front_cls(ns), rows_ptr(ns + 1, 0), rows;
 	std::vector<int64_t> front_off(ns), front_voff(ns);
 	std::vector<std::vector<int32_t> > loc_off(ns); // local scalar offset of each block row of the front
 	int64_t foff = 0, voff = 0;
@@ -351,9 +357,17 @@ void sparse_analyze(spp_ctx *ctx)
 		SPP_REQUIRE(h < 32768, SPP_E_UNSUPPORTED, "front too large for 16-bit local indices");
 		front_h[s] = h;
 		front_w[s] = w;
-		front_ld[s] = (h + 1) & ~1; // even: 16-byte aligned columns
+		// size class: the in-LDS kernels pad the pivot block to a multiple of 16 inside their image
+		// (hp16 <= 32 / 64 / 128); larger fronts live padded in HBM: pivot block rounded up to 128
+		// with identity so that the dense 128-block kernels apply unchanged
+		const int32_t w16 = (w + 15) & ~15, hp16 = (w16 + (h - w) + 15) & ~15;
+		int32_t cls = hp16 <= 32 ? 0 : (hp16 <= 64 ? 1 : (hp16 <= 128 ? 2 : 3));
+		front_cls[s] = cls;
+		front_pad[s] = (cls == 3) ? (((w + 127) & ~127) - w) : 0;
+		const int32_t hp = h + front_pad[s];
+		front_ld[s] = (hp + 1) & ~1; // even: 16-byte aligned columns
 		front_off[s] = foff;
-		foff += (int64_t)front_ld[s] * h;
+		foff += (int64_t)front_ld[s] * hp;
 		foff = (foff + 1) & ~int64_t(1);
 		front_voff[s] = voff;
 		voff += h;
@@ -366,6 +380,27 @@ void sparse_analyze(spp_ctx *ctx)
 			flops += (double)(h - j) * (double)(h - j);
 		nnz_r += (int64_t)w * h - (int64_t)w * (w - 1) / 2;
 	}
+	// regroup the level lists by size class
+	sp->h_cls_ptr.assign(sp->n_levels * 4 + 1, 0);
+	for(int64_t q = 0; q < ns; ++ q)
+		++ sp->h_cls_ptr[level[q] * 4 + front_cls[q] + 1];
+	for(int64_t q = 0; q < sp->n_levels * 4; ++ q)
+		sp->h_cls_ptr[q + 1] += sp->h_cls_ptr[q];
+	{
+		std::vector<int32_t> fill(sp->h_cls_ptr.begin(), sp->h_cls_ptr.end() - 1);
+		for(int64_t q = 0; q < ns; ++ q)
+			sp->h_level_fronts[fill[level[q] * 4 + front_cls[q]] ++] = (int32_t)q;
+	}
+	{
+		int64_t max_steps = 1;
+		for(int64_t q = 0; q < ns; ++ q)
+			if(front_cls[q] == 3)
+				max_steps = std::max<int64_t>(max_steps, (front_w[q] + front_pad[q]) / DENSE_NB);
+		dense_reserve(ctx, max_steps);
+	}
+	sp->h_front_ld = front_ld;
+	sp->h_front_pad = front_pad;
+	sp->h_front_cls = front_cls;
 	sp->front_doubles = foff;
 	sp->vbuf_doubles = voff;
 	sp->h_front_h = front_h;
@@ -389,6 +424,8 @@ void sparse_analyze(spp_ctx *ctx)
 				child_list[fill[sn_parent[s]] ++] = (int32_t)s;
 	}
 	child_list.resize(child_ptr[ns]);
+	sp->h_child_ptr = child_ptr;
+	sp->h_child_list = child_list;
 	for(int64_t s = 0; s < ns; ++ s) {
 		rel_ptr[s + 1] = rel_ptr[s];
 		const int32_t p = sn_parent[s];
@@ -437,17 +474,47 @@ void sparse_analyze(spp_ctx *ctx)
 		asm_dst.insert(asm_dst.end(), a_dst[s].begin(), a_dst[s].end());
 		asm_shape.insert(asm_shape.end(), a_shape[s].begin(), a_shape[s].end());
 	}
+	sp->h_asm_ptr = asm_ptr;
 	std::vector<int32_t> perm_scalar(st.n);
 	for(int64_t k = 0; k < nb; ++ k)
 		for(int32_t e = 0; e < pdim[k]; ++ e)
 			perm_scalar[pbase[k] + e] = (int32_t)(st.base[order[k]] + e);
 
+	if(getenv("SPP_VERBOSE")) {
+		int64_t hist[8] = {0}; // h <= 16, 32, 64, 128, 256, 512, 1024, more
+		double fl_hist[8] = {0};
+		int32_t hmax = 0, wmax = 0;
+		for(int64_t q = 0; q < ns; ++ q) {
+			int b = 0;
+			while(b < 7 && front_h[q] > (16 << b))
+				++ b;
+			++ hist[b];
+			double f = 0;
+			for(int32_t j = 0; j < front_w[q]; ++ j)
+				f += (double)(front_h[q] - j) * (double)(front_h[q] - j);
+			fl_hist[b] += f;
+			hmax = std::max(hmax, front_h[q]);
+			wmax = std::max(wmax, front_w[q]);
+		}
+		fprintf(stderr, "[spp] sparse analyze: nb %ld n %ld supernodes %ld levels %ld nnz(R) %ld flops %.3g front MB %.1f hmax %d wmax %d\n",
+			(long)nb, (long)st.n, (long)ns, (long)sp->n_levels, (long)nnz_r, flops, foff * 8e-6, hmax, wmax);
+		for(int b = 0; b < 8; ++ b)
+			fprintf(stderr, "[spp]   fronts with h <= %4d: %6ld  flops %.3g\n", 16 << b, (long)hist[b], fl_hist[b]);
+		for(int64_t l = 0; l < sp->n_levels; ++ l)
+			if(l < 4 || l + 12 >= sp->n_levels) {
+				int32_t hm = 0;
+				for(int32_t q = sp->h_level_ptr[l]; q < sp->h_level_ptr[l + 1]; ++ q)
+					hm = std::max(hm, front_h[sp->h_level_fronts[q]]);
+				fprintf(stderr, "[spp]   level %3ld: %5d fronts, max h %d\n", (long)l, sp->h_level_ptr[l + 1] - sp->h_level_ptr[l], hm);
+			}
+	}
 	hipStream_t s = ctx->stream;
 	sp->level_fronts.upload(sp->h_level_fronts, s);
 	sp->front_off.upload(front_off, s);
 	sp->front_h.upload(front_h, s);
 	sp->front_w.upload(front_w, s);
 	sp->front_ld.upload(front_ld, s);
+	sp->front_pad.upload(front_pad, s);
 	sp->front_voff.upload(front_voff, s);
 	sp->asm_ptr.upload(asm_ptr, s);
 	sp->asm_src.upload(asm_src, s);
@@ -463,119 +530,182 @@ void sparse_analyze(spp_ctx *ctx)
 	sp->fronts.reserve((size_t)std::max<int64_t>(foff, 2));
 	sp->vbuf.reserve((size_t)std::max<int64_t>(voff, 1));
 	sp->xperm.reserve((size_t)st.n);
-	sp->info.reserve(4);
 	SPP_HIP_CHECK(hipStreamSynchronize(s));
 	(void)BIG_FRONT_H;
 }
 
 // --------------------------------------------------------------------------------------------------
-// kernels: one workgroup (256 threads) per front
+// numeric kernels
 // --------------------------------------------------------------------------------------------------
 constexpr int FT = 256;
 
-__global__ __launch_bounds__(FT)
-void front_factor_kernel(const int32_t *__restrict__ level_fronts, const int64_t *__restrict__ front_off,
+// local (unpadded) front index -> index in a padded image: `pad` entries are inserted after the w pivots
+__device__ __forceinline__ int padded(int r, int w, int pad) { return r < w ? r : r + pad; }
+
+// One workgroup per front, the whole front in LDS (image HP x HP, column stride HP + 1, pivot block
+// padded with identity to a multiple of 16). Blocked right-looking partial factorization, 16-wide
+// panels: A  16 x 16 diagonal tile factored + inverted in registers by wave 0 (diag_tile_factor)
+//         B  row panel X = Dinv^T Y, one 16 x 16 MFMA tile per wave
+//         C  trailing update T[I,K] -= P_I^T P_K on MFMA f64 16x16x4
+// The result is written back to the front's HBM buffer in the plain (unpadded) layout.
+template <int HP, int NTH>
+__global__ __launch_bounds__(NTH)
+void front_lds_kernel(const int32_t *__restrict__ list, const int64_t *__restrict__ front_off,
 	const int32_t *__restrict__ front_h, const int32_t *__restrict__ front_w, const int32_t *__restrict__ front_ld,
-	const int32_t *__restrict__ asm_ptr, const int64_t *__restrict__ asm_src, const int32_t *__restrict__ asm_dst,
-	const int32_t *__restrict__ asm_shape, const int32_t *__restrict__ child_ptr, const int32_t *__restrict__ child_list,
-	const int32_t *__restrict__ rel_ptr, const int32_t *__restrict__ rel, const double *__restrict__ vals,
-	double *__restrict__ fronts, int *__restrict__ info)
+	const int32_t *__restrict__ front_pad, const int32_t *__restrict__ asm_ptr, const int64_t *__restrict__ asm_src,
+	const int32_t *__restrict__ asm_dst, const int32_t *__restrict__ asm_shape, const int32_t *__restrict__ child_ptr,
+	const int32_t *__restrict__ child_list, const int32_t *__restrict__ rel_ptr, const int32_t *__restrict__ rel,
+	const double *__restrict__ vals, double *__restrict__ fronts, int *__restrict__ info)
 {
-	const int s = level_fronts[blockIdx.x];
+	constexpr int TSF = HP + 1, NW = NTH / 64;
+	extern __shared__ double fsm[];
+	double *T = fsm;                    // HP x TSF image
+	double *Dv = T + HP * TSF;          // Dinv of the current diagonal tile
+	double *Gd = Dv + 16 * PT;          // (unused by the fronts, written by diag_tile_factor)
+	double *dinv = Gd + 16 * PT;        // HP
+	int *fail = (int*)(dinv + HP);
+	const int s = list[blockIdx.x];
 	const int h = front_h[s], w = front_w[s], ld = front_ld[s];
+	const int w16 = (w + 15) & ~15, pad = w16 - w, hp = h + pad, nt = (hp + 15) >> 4;
 	double *F = fronts + front_off[s];
-	const int tid = threadIdx.x;
-	__shared__ double rowj[2048 + 8]; // staged pivot row (h <= 2048 fast path; else read from global)
-	__shared__ double pinv_s;
-	// ---- zero the upper triangle (column-wise, coalesced)
-	for(int64_t e = tid; e < (int64_t)ld * h; e += FT)
-		F[e] = 0.0;
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int l15 = lane & 15, l4 = lane >> 4;
+	for(int e = tid; e < HP * TSF; e += NTH)
+		T[e] = 0.0;
+	if(tid == 0)
+		*fail = 0;
 	__syncthreads();
+	if(tid >= w && tid < w16)
+		T[tid + tid * TSF] = 1.0; // identity padding of the pivot block
 	// ---- blocks of Lambda
-	for(int q = asm_ptr[s]; q < asm_ptr[s + 1]; ++ q) {
+	for(int q = asm_ptr[s] + wave; q < asm_ptr[s + 1]; q += NW) {
 		const int64_t so = asm_src[q];
 		const double *src = vals + (so >> 1);
-		const int dr = asm_dst[q] & 0xffff, dc = asm_dst[q] >> 16;
+		const int dr = padded(asm_dst[q] & 0xffff, w, pad), dc = padded(asm_dst[q] >> 16, w, pad);
 		const int nr = asm_shape[q] & 0xff, ncol = asm_shape[q] >> 8;
-		if(tid < nr * ncol) {
-			const int r = tid % nr, c = tid / nr;
-			// destination (r, c) of an nr x ncol block; source is nr x ncol col-major, or its
-			// transpose (ncol x nr col-major) when the permutation flipped the block
-			const double v = (so & 1) ? src[c + ncol * r] : src[r + nr * c];
-			F[(dr + r) + (int64_t)(dc + c) * ld] = v;
+		if(lane < nr * ncol) {
+			const int r = lane % nr, c = lane / nr;
+			T[(dr + r) + (dc + c) * TSF] = (so & 1) ? src[c + ncol * r] : src[r + nr * c];
 		}
 	}
 	__syncthreads();
 	// ---- extend-add of the children's update matrices, children in list order
 	for(int cq = child_ptr[s]; cq < child_ptr[s + 1]; ++ cq) {
 		const int c = child_list[cq];
-		const int hc = front_h[c], wc = front_w[c], ldc = front_ld[c];
+		const int hc = front_h[c], wc = front_w[c], ldc = front_ld[c], oc = wc + front_pad[c];
 		const double *Fc = fronts + front_off[c];
 		const int32_t *rl = rel + rel_ptr[c];
 		const int m = hc - wc;
-		// upper triangle of the m x m update block: (i <= j)
-		for(int64_t e = tid; e < (int64_t)m * m; e += FT) {
-			const int i = (int)(e % m), j = (int)(e / m);
+		for(int e = tid; e < m * m; e += NTH) {
+			const int i = e % m, j = e / m;
 			if(i <= j)
-				F[rl[i] + (int64_t)rl[j] * ld] += Fc[(wc + i) + (int64_t)(wc + j) * ldc];
+				T[padded(rl[i], w, pad) + padded(rl[j], w, pad) * TSF] += Fc[(oc + i) + (int64_t)(oc + j) * ldc];
 		}
 		__syncthreads();
 	}
-	// ---- partial factorization, square-root free (one scaling pass at the end)
-	for(int j = 0; j < w; ++ j) {
-		// stage row j (columns j .. h-1)
-		for(int c = j + tid; c < h; c += FT)
-			rowj[(c - j) & 2047] = F[j + (int64_t)c * ld];
-		if(h - j > 2048) { /* very large front: rows are read from global below */ }
+	// ---- blocked partial factorization
+	const int npan = w16 >> 4;
+	for(int J = 0; J < npan; ++ J) {
+		const int j0 = J * 16;
+		if(wave == 0)
+			diag_tile_factor<TSF>(T, Dv, Gd, dinv, j0, lane, fail, info, 0);
 		__syncthreads();
-		const double p = rowj[0];
-		if(!(p > 0)) {
-			if(tid == 0)
-				atomicMax(info, 1);
-			return; // uniform
+		if(*fail)
+			return;
+		for(int K = J + 1 + wave; K < nt; K += NW) { // B: row panel
+			double *Y = T + j0 + (K * 16) * TSF;
+			const v4f64 x = tile_atb(Dv, 1, PT, Y, 1, TSF, lane);
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+#pragma unroll
+			for(int r = 0; r < 4; ++ r)
+				Y[(l4 + 4 * r) + l15 * TSF] = x[r];
 		}
-		const double pinv = 1.0 / p;
-		const int m = h - j - 1; // trailing size
-		// element (i, c), j < i <= c < h ; threads sweep columns, consecutive threads on consecutive rows
-		if(h - j <= 2048) {
-			for(int64_t e = tid; e < (int64_t)m * m; e += FT) {
-				const int i = (int)(e % m), c = (int)(e / m);
-				if(i <= c)
-					F[(j + 1 + i) + (int64_t)(j + 1 + c) * ld] -= rowj[1 + i] * pinv * rowj[1 + c];
+		__syncthreads();
+		{ // C: trailing update, tiles (I <= K) of the remaining (nt - J - 1) tile rows
+			const int nI = nt - 1 - J, nR = nI * (nI + 1) / 2;
+			for(int q = wave; q < nR; q += NW) {
+				int a = 0, rem = q;
+				while(rem >= nI - a) {
+					rem -= nI - a;
+					++ a;
+				}
+				const int I = J + 1 + a, K = I + rem;
+				const v4f64 d = tile_atb(T + j0 + (I * 16) * TSF, 1, TSF, T + j0 + (K * 16) * TSF, 1, TSF, lane);
+				double *D = T + (I * 16) + (K * 16) * TSF;
+#pragma unroll
+				for(int r = 0; r < 4; ++ r)
+					D[(l4 + 4 * r) + l15 * TSF] -= d[r];
 			}
-		} else {
-			for(int64_t e = tid; e < (int64_t)m * m; e += FT) {
-				const int i = (int)(e % m), c = (int)(e / m);
-				if(i <= c)
-					F[(j + 1 + i) + (int64_t)(j + 1 + c) * ld] -=
-						F[j + (int64_t)(j + 1 + i) * ld] * pinv * F[j + (int64_t)(j + 1 + c) * ld];
-			}
 		}
 		__syncthreads();
 	}
-	(void)pinv_s;
-	// ---- scale the pivot rows: R[j][c] = F[j][c] / sqrt(p_j)
-	for(int64_t e = tid; e < (int64_t)w * h; e += FT) {
-		const int j = (int)(e % w), c = (int)(e / w);
-		if(c > j)
-			F[j + (int64_t)c * ld] *= 1.0 / sqrt(F[j + (int64_t)j * ld]);
+	// ---- write back the upper triangle in the plain layout
+	for(int e = tid; e < h * h; e += NTH) {
+		const int r = e % h, c = e / h;
+		if(r <= c)
+			F[r + (int64_t)c * ld] = T[padded(r, w, pad) + padded(c, w, pad) * TSF];
 	}
-	__syncthreads();
-	for(int j = tid; j < w; j += FT)
-		F[j + (int64_t)j * ld] = sqrt(F[j + (int64_t)j * ld]);
+}
+
+// ---- big fronts (image does not fit LDS): assembled in HBM in the padded layout, factored by the
+// multi-workgroup dense kernels (spp_dense.hip)
+__global__ __launch_bounds__(256)
+void bigfront_scatter_kernel(int s, const int64_t *__restrict__ front_off, const int32_t *__restrict__ front_w,
+	const int32_t *__restrict__ front_ld, const int32_t *__restrict__ front_pad, const int32_t *__restrict__ asm_ptr,
+	const int64_t *__restrict__ asm_src, const int32_t *__restrict__ asm_dst, const int32_t *__restrict__ asm_shape,
+	const double *__restrict__ vals, double *__restrict__ fronts)
+{
+	const int w = front_w[s], ld = front_ld[s], pad = front_pad[s];
+	double *F = fronts + front_off[s];
+	const int tid = threadIdx.x, lane = tid & 63;
+	if(blockIdx.x == 0) // identity padding of the pivot block
+		for(int i = w + tid; i < w + pad; i += 256)
+			F[i + (int64_t)i * ld] = 1.0;
+	const int q = asm_ptr[s] + blockIdx.x * 4 + (tid >> 6);
+	if(q >= asm_ptr[s + 1])
+		return;
+	const int64_t so = asm_src[q];
+	const double *src = vals + (so >> 1);
+	const int dr = padded(asm_dst[q] & 0xffff, w, pad), dc = padded(asm_dst[q] >> 16, w, pad);
+	const int nr = asm_shape[q] & 0xff, ncol = asm_shape[q] >> 8;
+	if(lane < nr * ncol) {
+		const int r = lane % nr, c = lane / nr;
+		F[(dr + r) + (int64_t)(dc + c) * ld] = (so & 1) ? src[c + ncol * r] : src[r + nr * c];
+	}
+}
+
+__global__ __launch_bounds__(256)
+void bigfront_extend_kernel(int s, int c, const int64_t *__restrict__ front_off, const int32_t *__restrict__ front_h,
+	const int32_t *__restrict__ front_w, const int32_t *__restrict__ front_ld, const int32_t *__restrict__ front_pad,
+	const int32_t *__restrict__ rel_ptr, const int32_t *__restrict__ rel, double *__restrict__ fronts)
+{
+	const int w = front_w[s], ld = front_ld[s], pad = front_pad[s];
+	double *F = fronts + front_off[s];
+	const int hc = front_h[c], wc = front_w[c], ldc = front_ld[c], oc = wc + front_pad[c];
+	const double *Fc = fronts + front_off[c];
+	const int32_t *rl = rel + rel_ptr[c];
+	const int m = hc - wc;
+	const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	if(e >= (int64_t)m * m)
+		return;
+	const int i = (int)(e % m), j = (int)(e / m);
+	if(i <= j)
+		F[padded(rl[i], w, pad) + (int64_t)padded(rl[j], w, pad) * ld] += Fc[(oc + i) + (int64_t)(oc + j) * ldc];
 }
 
 // forward substitution R^T y = b, leaves -> root. v = work vector of the front (length h).
 __global__ __launch_bounds__(FT)
 void front_fwd_kernel(const int32_t *__restrict__ level_fronts, const int64_t *__restrict__ front_off,
 	const int32_t *__restrict__ front_h, const int32_t *__restrict__ front_w, const int32_t *__restrict__ front_ld,
+	const int32_t *__restrict__ front_pad,
 	const int64_t *__restrict__ front_voff, const int32_t *__restrict__ child_ptr, const int32_t *__restrict__ child_list,
 	const int32_t *__restrict__ rel_ptr, const int32_t *__restrict__ rel, const int32_t *__restrict__ rows_ptr,
 	const int32_t *__restrict__ rows, const double *__restrict__ fronts, double *__restrict__ vbuf,
 	double *__restrict__ xperm)
 {
 	const int s = level_fronts[blockIdx.x];
-	const int h = front_h[s], w = front_w[s], ld = front_ld[s];
+	const int h = front_h[s], w = front_w[s], ld = front_ld[s], pad = front_pad[s];
 	const double *F = fronts + front_off[s];
 	double *v = vbuf + front_voff[s];
 	const int32_t *rw = rows + rows_ptr[s];
@@ -598,7 +728,7 @@ void front_fwd_kernel(const int32_t *__restrict__ level_fronts, const int64_t *_
 		if(tid == 0)
 			v[j] = yj;
 		for(int c = j + 1 + tid; c < h; c += FT)
-			v[c] -= F[j + (int64_t)c * ld] * yj;
+			v[c] -= F[j + (int64_t)padded(c, w, pad) * ld] * yj;
 		__syncthreads();
 	}
 	for(int c = tid; c < w; c += FT)
@@ -609,11 +739,12 @@ void front_fwd_kernel(const int32_t *__restrict__ level_fronts, const int64_t *_
 __global__ __launch_bounds__(FT)
 void front_bwd_kernel(const int32_t *__restrict__ level_fronts, const int64_t *__restrict__ front_off,
 	const int32_t *__restrict__ front_h, const int32_t *__restrict__ front_w, const int32_t *__restrict__ front_ld,
+	const int32_t *__restrict__ front_pad,
 	const int64_t *__restrict__ front_voff, const int32_t *__restrict__ rows_ptr, const int32_t *__restrict__ rows,
 	const double *__restrict__ fronts, double *__restrict__ vbuf, double *__restrict__ xperm)
 {
 	const int s = level_fronts[blockIdx.x];
-	const int h = front_h[s], w = front_w[s], ld = front_ld[s];
+	const int h = front_h[s], w = front_w[s], ld = front_ld[s], pad = front_pad[s];
 	const double *F = fronts + front_off[s];
 	double *v = vbuf + front_voff[s];
 	const int32_t *rw = rows + rows_ptr[s];
@@ -626,7 +757,7 @@ void front_bwd_kernel(const int32_t *__restrict__ level_fronts, const int64_t *_
 		-- j;
 		double sum = 0;
 		for(int c = j + 1 + tid; c < h; c += FT)
-			sum += F[j + (int64_t)c * ld] * v[c];
+			sum += F[j + (int64_t)padded(c, w, pad) * ld] * v[c];
 #pragma unroll
 		for(int off = 32; off > 0; off >>= 1)
 			sum += __shfl_xor(sum, off);
@@ -661,7 +792,23 @@ __global__ void scatter_perm_kernel(int64_t n, const int32_t *__restrict__ perm,
 		dst[perm[i]] = src[i];
 }
 
-__global__ void zero_info_kernel(int *info) { info[0] = 0; }
+template <int HP, int NTH>
+static void launch_front_lds(spp_ctx *ctx, SparsePlan *sp, int32_t b, int32_t e, const double *d_vals)
+{
+	if(e <= b)
+		return;
+	const size_t lds = ((size_t)HP * (HP + 1) + 2 * 16 * PT + HP + 8) * sizeof(double);
+	static bool attr = false;
+	if(!attr) {
+		SPP_HIP_CHECK(hipFuncSetAttribute((const void*)front_lds_kernel<HP, NTH>,
+			hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		attr = true;
+	}
+	hipLaunchKernelGGL((front_lds_kernel<HP, NTH>), dim3((unsigned)(e - b)), dim3(NTH), lds, ctx->stream,
+		sp->level_fronts.p + b, sp->front_off.p, sp->front_h.p, sp->front_w.p, sp->front_ld.p, sp->front_pad.p,
+		sp->asm_ptr.p, sp->asm_src.p, sp->asm_dst.p, sp->asm_shape.p, sp->child_ptr.p, sp->child_list.p,
+		sp->rel_ptr.p, sp->rel.p, d_vals, sp->fronts.p, ctx->dense.info.p);
+}
 
 int sparse_factor_solve(spp_ctx *ctx, const double *d_vals, double *d_rhs)
 {
@@ -669,37 +816,53 @@ int sparse_factor_solve(spp_ctx *ctx, const double *d_vals, double *d_rhs)
 	SPP_REQUIRE(sp, SPP_E_STATE, "sparse plan missing");
 	hipStream_t s = ctx->stream;
 	const unsigned gn = (unsigned)((sp->n + 255) / 256);
-	hipLaunchKernelGGL(zero_info_kernel, dim3(1), dim3(1), 0, s, sp->info.p);
+	dense_info_reset(ctx);
 	phase_begin(ctx, SPP_PHASE_FACTOR);
 	for(int64_t l = 0; l < sp->n_levels; ++ l) {
-		const int32_t b = sp->h_level_ptr[l], e = sp->h_level_ptr[l + 1];
-		hipLaunchKernelGGL(front_factor_kernel, dim3((unsigned)(e - b)), dim3(FT), 0, s,
-			sp->level_fronts.p + b, sp->front_off.p, sp->front_h.p, sp->front_w.p, sp->front_ld.p,
-			sp->asm_ptr.p, sp->asm_src.p, sp->asm_dst.p, sp->asm_shape.p, sp->child_ptr.p, sp->child_list.p,
-			sp->rel_ptr.p, sp->rel.p, d_vals, sp->fronts.p, sp->info.p);
+		const int32_t *cp = sp->h_cls_ptr.data() + l * 4;
+		launch_front_lds<32, 64>(ctx, sp, cp[0], cp[1], d_vals);
+		launch_front_lds<64, 256>(ctx, sp, cp[1], cp[2], d_vals);
+		launch_front_lds<128, 512>(ctx, sp, cp[2], cp[3], d_vals);
+		for(int32_t q = cp[3]; q < cp[4]; ++ q) { // big fronts, one after the other
+			const int32_t f = sp->h_level_fronts[q];
+			const int32_t h = sp->h_front_h[f], w = sp->h_front_w[f], pad = sp->h_front_pad[f], ld = sp->h_front_ld[f];
+			const int32_t hp = h + pad;
+			double *F = sp->fronts.p + sp->h_front_off[f];
+			SPP_HIP_CHECK(hipMemsetAsync(F, 0, (size_t)ld * hp * sizeof(double), s));
+			const int32_t nasm = sp->h_asm_ptr[f + 1] - sp->h_asm_ptr[f];
+			hipLaunchKernelGGL(bigfront_scatter_kernel, dim3((unsigned)((nasm + 3) / 4 + 1)), dim3(256), 0, s,
+				f, sp->front_off.p, sp->front_w.p, sp->front_ld.p, sp->front_pad.p, sp->asm_ptr.p, sp->asm_src.p,
+				sp->asm_dst.p, sp->asm_shape.p, d_vals, sp->fronts.p);
+			for(int32_t cq = sp->h_child_ptr[f]; cq < sp->h_child_ptr[f + 1]; ++ cq) {
+				const int32_t c = sp->h_child_list[cq];
+				const int64_t m = sp->h_front_h[c] - sp->h_front_w[c];
+				if(m > 0)
+					hipLaunchKernelGGL(bigfront_extend_kernel, dim3((unsigned)((m * m + 255) / 256)), dim3(256), 0, s,
+						f, c, sp->front_off.p, sp->front_h.p, sp->front_w.p, sp->front_ld.p, sp->front_pad.p,
+						sp->rel_ptr.p, sp->rel.p, sp->fronts.p);
+			}
+			dense_factor_steps(ctx, F, ld, w + pad, hp, hp, (w + pad) / DENSE_NB, false);
+		}
 	}
 	phase_end(ctx, SPP_PHASE_FACTOR);
 	SPP_HIP_CHECK(hipGetLastError());
-	int h_info = 0;
-	SPP_HIP_CHECK(hipMemcpyAsync(&h_info, sp->info.p, sizeof(int), hipMemcpyDeviceToHost, s));
-	SPP_HIP_CHECK(hipStreamSynchronize(s));
-	if(h_info)
+	if(dense_info_fetch(ctx))
 		return SPP_NOT_POSDEF;
 	phase_begin(ctx, SPP_PHASE_TRISOLVE);
 	hipLaunchKernelGGL(gather_perm_kernel, dim3(gn), dim3(256), 0, s, sp->n, sp->perm_scalar.p, d_rhs, sp->xperm.p);
 	for(int64_t l = 0; l < sp->n_levels; ++ l) {
 		const int32_t b = sp->h_level_ptr[l], e = sp->h_level_ptr[l + 1];
 		hipLaunchKernelGGL(front_fwd_kernel, dim3((unsigned)(e - b)), dim3(FT), 0, s,
-			sp->level_fronts.p + b, sp->front_off.p, sp->front_h.p, sp->front_w.p, sp->front_ld.p, sp->front_voff.p,
-			sp->child_ptr.p, sp->child_list.p, sp->rel_ptr.p, sp->rel.p, sp->rows_ptr.p, sp->rows.p,
+			sp->level_fronts.p + b, sp->front_off.p, sp->front_h.p, sp->front_w.p, sp->front_ld.p, sp->front_pad.p,
+			sp->front_voff.p, sp->child_ptr.p, sp->child_list.p, sp->rel_ptr.p, sp->rel.p, sp->rows_ptr.p, sp->rows.p,
 			sp->fronts.p, sp->vbuf.p, sp->xperm.p);
 	}
 	for(int64_t l = sp->n_levels; l > 0;) {
 		-- l;
 		const int32_t b = sp->h_level_ptr[l], e = sp->h_level_ptr[l + 1];
 		hipLaunchKernelGGL(front_bwd_kernel, dim3((unsigned)(e - b)), dim3(FT), 0, s,
-			sp->level_fronts.p + b, sp->front_off.p, sp->front_h.p, sp->front_w.p, sp->front_ld.p, sp->front_voff.p,
-			sp->rows_ptr.p, sp->rows.p, sp->fronts.p, sp->vbuf.p, sp->xperm.p);
+			sp->level_fronts.p + b, sp->front_off.p, sp->front_h.p, sp->front_w.p, sp->front_ld.p, sp->front_pad.p,
+			sp->front_voff.p, sp->rows_ptr.p, sp->rows.p, sp->fronts.p, sp->vbuf.p, sp->xperm.p);
 	}
 	hipLaunchKernelGGL(scatter_perm_kernel, dim3(gn), dim3(256), 0, s, sp->n, sp->perm_scalar.p, sp->xperm.p, d_rhs);
 	phase_end(ctx, SPP_PHASE_TRISOLVE);

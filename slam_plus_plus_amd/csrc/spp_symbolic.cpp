@@ -57,10 +57,8 @@ bool schur_applicable(const Structure &st, int *dp_out, int *dl_out)
 				return false; // landmark-landmark block: C not block diagonal
 		}
 	}
-	// LinearSolver_Schur.h:1586: guided cut must leave fewer poses than half of the vertices
-	if(n_lm == 0 || (st.nb - n_lm) >= (st.nb + 1) / 2 + 0 * n_lm)
-		if(n_lm == 0)
-			return false;
+	if(n_lm == 0)
+		return false;
 	*dp_out = dp;
 	*dl_out = dl;
 	return true;
@@ -290,6 +288,8 @@ void build_schur_plan(spp_ctx *ctx)
 	sp.xw.reserve((size_t)std::max<int64_t>(1, no) * dp);
 	sp.partial.reserve((size_t)std::max<int32_t>(1, n_slots) * dp * dp);
 	SPP_HIP_CHECK(hipStreamSynchronize(s)); // host vectors die here
+
+	dense_reserve(ctx, (sp.n_red + DENSE_NB - 1) / DENSE_NB);
 
 	// ---- accounting (SURVEY 8d "Schur" + "Dense reduced solve")
 	const double n = (double)sp.n_red;
