@@ -43,7 +43,7 @@ struct SparsePlan {
 	std::vector<int64_t> h_front_off;
 	std::vector<int32_t> h_level_fronts;
 	std::vector<int32_t> h_front_ld, h_front_pad, h_front_cls;
-	std::vector<int32_t> h_cls_ptr;            // [n_levels * 4 + 1]: fronts of (level, class) in level_fronts
+	std::vector<int32_t> h_cls_ptr;            // [n_levels * NCLS + 1]: fronts of (level, class) in level_fronts
 	std::vector<int32_t> h_child_ptr, h_child_list, h_asm_ptr;
 	// device
 	DevBuf<int32_t> level_fronts;              // fronts grouped by level
@@ -160,7 +160,8 @@ int64_t sparse_info(const spp_ctx *ctx, int what)
 	return 0;
 }
 
-static const int BIG_FRONT_H = 1 << 30; // threshold (scalar height) above which a front uses the dense kernels
+static const int NCLS = 5;
+static const int MID_FRONT_MAX = 384; // padded height up to which ONE workgroup factors a front in place in HBM
 
 void sparse_analyze(spp_ctx *ctx)
 {
@@ -361,10 +362,11 @@ void sparse_analyze(spp_ctx *ctx)
 		// (hp16 <= 32 / 64 / 128); larger fronts live padded in HBM: pivot block rounded up to 128
 		// with identity so that the dense 128-block kernels apply unchanged
 		const int32_t w16 = (w + 15) & ~15, hp16 = (w16 + (h - w) + 15) & ~15;
-		int32_t cls = hp16 <= 32 ? 0 : (hp16 <= 64 ? 1 : (hp16 <= 128 ? 2 : 3));
+		int32_t cls = hp16 <= 32 ? 0 : (hp16 <= 64 ? 1 : (hp16 <= 128 ? 2 : (hp16 <= MID_FRONT_MAX ? 3 : 4)));
 		front_cls[s] = cls;
-		front_pad[s] = (cls == 3) ? (((w + 127) & ~127) - w) : 0;
-		const int32_t hp = h + front_pad[s];
+		front_pad[s] = (cls == 4) ? (((w + 127) & ~127) - w) : (cls == 3 ? w16 - w : 0);
+		// class 3 works on whole 16 x 16 tiles in place: its HBM image is rounded up to tiles
+		const int32_t hp = (cls == 3) ? hp16 : h + front_pad[s];
 		front_ld[s] = (hp + 1) & ~1; // even: 16-byte aligned columns
 		front_off[s] = foff;
 		foff += (int64_t)front_ld[s] * hp;
@@ -381,20 +383,20 @@ void sparse_analyze(spp_ctx *ctx)
 		nnz_r += (int64_t)w * h - (int64_t)w * (w - 1) / 2;
 	}
 	// regroup the level lists by size class
-	sp->h_cls_ptr.assign(sp->n_levels * 4 + 1, 0);
+	sp->h_cls_ptr.assign(sp->n_levels * NCLS + 1, 0);
 	for(int64_t q = 0; q < ns; ++ q)
-		++ sp->h_cls_ptr[level[q] * 4 + front_cls[q] + 1];
-	for(int64_t q = 0; q < sp->n_levels * 4; ++ q)
+		++ sp->h_cls_ptr[level[q] * NCLS + front_cls[q] + 1];
+	for(int64_t q = 0; q < sp->n_levels * NCLS; ++ q)
 		sp->h_cls_ptr[q + 1] += sp->h_cls_ptr[q];
 	{
 		std::vector<int32_t> fill(sp->h_cls_ptr.begin(), sp->h_cls_ptr.end() - 1);
 		for(int64_t q = 0; q < ns; ++ q)
-			sp->h_level_fronts[fill[level[q] * 4 + front_cls[q]] ++] = (int32_t)q;
+			sp->h_level_fronts[fill[level[q] * NCLS + front_cls[q]] ++] = (int32_t)q;
 	}
 	{
 		int64_t max_steps = 1;
 		for(int64_t q = 0; q < ns; ++ q)
-			if(front_cls[q] == 3)
+			if(front_cls[q] == 4)
 				max_steps = std::max<int64_t>(max_steps, (front_w[q] + front_pad[q]) / DENSE_NB);
 		dense_reserve(ctx, max_steps);
 	}
@@ -531,7 +533,6 @@ void sparse_analyze(spp_ctx *ctx)
 	sp->vbuf.reserve((size_t)std::max<int64_t>(voff, 1));
 	sp->xperm.reserve((size_t)st.n);
 	SPP_HIP_CHECK(hipStreamSynchronize(s));
-	(void)BIG_FRONT_H;
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -548,7 +549,7 @@ __device__ __forceinline__ int padded(int r, int w, int pad) { return r < w ? r 
 //         B  row panel X = Dinv^T Y, one 16 x 16 MFMA tile per wave
 //         C  trailing update T[I,K] -= P_I^T P_K on MFMA f64 16x16x4
 // The result is written back to the front's HBM buffer in the plain (unpadded) layout.
-template <int HP, int NTH>
+template <int HP, int NTH, bool GMEM>
 __global__ __launch_bounds__(NTH)
 void front_lds_kernel(const int32_t *__restrict__ list, const int64_t *__restrict__ front_off,
 	const int32_t *__restrict__ front_h, const int32_t *__restrict__ front_w, const int32_t *__restrict__ front_ld,
@@ -557,26 +558,34 @@ void front_lds_kernel(const int32_t *__restrict__ list, const int64_t *__restric
 	const int32_t *__restrict__ child_list, const int32_t *__restrict__ rel_ptr, const int32_t *__restrict__ rel,
 	const double *__restrict__ vals, double *__restrict__ fronts, int *__restrict__ info)
 {
-	constexpr int TSF = HP + 1, NW = NTH / 64;
+	// GMEM: the image is the front's own HBM buffer (already in the 16-padded layout, stride ld);
+	// otherwise an LDS image of HP x (HP + 1) doubles
+	constexpr int NW = NTH / 64;
 	extern __shared__ double fsm[];
-	double *T = fsm;                    // HP x TSF image
-	double *Dv = T + HP * TSF;          // Dinv of the current diagonal tile
-	double *Gd = Dv + 16 * PT;          // (unused by the fronts, written by diag_tile_factor)
-	double *dinv = Gd + 16 * PT;        // HP
-	int *fail = (int*)(dinv + HP);
 	const int s = list[blockIdx.x];
 	const int h = front_h[s], w = front_w[s], ld = front_ld[s];
 	const int w16 = (w + 15) & ~15, pad = w16 - w, hp = h + pad, nt = (hp + 15) >> 4;
 	double *F = fronts + front_off[s];
+	const int TSF = GMEM ? ld : HP + 1;
+	double *T = GMEM ? F : fsm;                                   // image
+	double *Dv = GMEM ? fsm : fsm + HP * (HP + 1);                // Dinv of the current diagonal tile
+	double *Gd = Dv + 16 * PT;          // (unused by the fronts, written by diag_tile_factor)
+	double *dinv = Gd + 16 * PT;        // HP
+	int *fail = (int*)(dinv + HP);
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int l15 = lane & 15, l4 = lane >> 4;
-	for(int e = tid; e < HP * TSF; e += NTH)
-		T[e] = 0.0;
+	if(GMEM) {
+		for(int64_t e = tid; e < (int64_t)ld * (nt * 16); e += NTH)
+			T[e] = 0.0;
+	} else {
+		for(int e = tid; e < HP * (HP + 1); e += NTH)
+			T[e] = 0.0;
+	}
 	if(tid == 0)
 		*fail = 0;
 	__syncthreads();
 	if(tid >= w && tid < w16)
-		T[tid + tid * TSF] = 1.0; // identity padding of the pivot block
+		T[tid + (int64_t)tid * TSF] = 1.0; // identity padding of the pivot block
 	// ---- blocks of Lambda
 	for(int q = asm_ptr[s] + wave; q < asm_ptr[s + 1]; q += NW) {
 		const int64_t so = asm_src[q];
@@ -608,7 +617,7 @@ void front_lds_kernel(const int32_t *__restrict__ list, const int64_t *__restric
 	for(int J = 0; J < npan; ++ J) {
 		const int j0 = J * 16;
 		if(wave == 0)
-			diag_tile_factor<TSF>(T, Dv, Gd, dinv, j0, lane, fail, info, 0);
+			diag_tile_factor_rt(TSF, T, Dv, Gd, dinv, j0, lane, fail, info, 0);
 		__syncthreads();
 		if(*fail)
 			return;
@@ -640,6 +649,8 @@ void front_lds_kernel(const int32_t *__restrict__ list, const int64_t *__restric
 		}
 		__syncthreads();
 	}
+	if(GMEM)
+		return; // factored in place
 	// ---- write back the upper triangle in the plain layout
 	for(int e = tid; e < h * h; e += NTH) {
 		const int r = e % h, c = e / h;
@@ -792,19 +803,19 @@ __global__ void scatter_perm_kernel(int64_t n, const int32_t *__restrict__ perm,
 		dst[perm[i]] = src[i];
 }
 
-template <int HP, int NTH>
+template <int HP, int NTH, bool GMEM>
 static void launch_front_lds(spp_ctx *ctx, SparsePlan *sp, int32_t b, int32_t e, const double *d_vals)
 {
 	if(e <= b)
 		return;
-	const size_t lds = ((size_t)HP * (HP + 1) + 2 * 16 * PT + HP + 8) * sizeof(double);
+	const size_t lds = ((GMEM ? 0 : (size_t)HP * (HP + 1)) + 2 * 16 * PT + HP + 8) * sizeof(double);
 	static bool attr = false;
 	if(!attr) {
-		SPP_HIP_CHECK(hipFuncSetAttribute((const void*)front_lds_kernel<HP, NTH>,
+		SPP_HIP_CHECK(hipFuncSetAttribute((const void*)front_lds_kernel<HP, NTH, GMEM>,
 			hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 		attr = true;
 	}
-	hipLaunchKernelGGL((front_lds_kernel<HP, NTH>), dim3((unsigned)(e - b)), dim3(NTH), lds, ctx->stream,
+	hipLaunchKernelGGL((front_lds_kernel<HP, NTH, GMEM>), dim3((unsigned)(e - b)), dim3(NTH), lds, ctx->stream,
 		sp->level_fronts.p + b, sp->front_off.p, sp->front_h.p, sp->front_w.p, sp->front_ld.p, sp->front_pad.p,
 		sp->asm_ptr.p, sp->asm_src.p, sp->asm_dst.p, sp->asm_shape.p, sp->child_ptr.p, sp->child_list.p,
 		sp->rel_ptr.p, sp->rel.p, d_vals, sp->fronts.p, ctx->dense.info.p);
@@ -819,11 +830,12 @@ int sparse_factor_solve(spp_ctx *ctx, const double *d_vals, double *d_rhs)
 	dense_info_reset(ctx);
 	phase_begin(ctx, SPP_PHASE_FACTOR);
 	for(int64_t l = 0; l < sp->n_levels; ++ l) {
-		const int32_t *cp = sp->h_cls_ptr.data() + l * 4;
-		launch_front_lds<32, 64>(ctx, sp, cp[0], cp[1], d_vals);
-		launch_front_lds<64, 256>(ctx, sp, cp[1], cp[2], d_vals);
-		launch_front_lds<128, 512>(ctx, sp, cp[2], cp[3], d_vals);
-		for(int32_t q = cp[3]; q < cp[4]; ++ q) { // big fronts, one after the other
+		const int32_t *cp = sp->h_cls_ptr.data() + l * NCLS;
+		launch_front_lds<32, 64, false>(ctx, sp, cp[0], cp[1], d_vals);
+		launch_front_lds<64, 256, false>(ctx, sp, cp[1], cp[2], d_vals);
+		launch_front_lds<128, 512, false>(ctx, sp, cp[2], cp[3], d_vals);
+		launch_front_lds<MID_FRONT_MAX, 1024, true>(ctx, sp, cp[3], cp[4], d_vals); // in place in HBM
+		for(int32_t q = cp[4]; q < cp[5]; ++ q) { // big fronts, one after the other
 			const int32_t f = sp->h_level_fronts[q];
 			const int32_t h = sp->h_front_h[f], w = sp->h_front_w[f], pad = sp->h_front_pad[f], ld = sp->h_front_ld[f];
 			const int32_t hp = h + pad;

@@ -35,8 +35,7 @@ __device__ __forceinline__ v4f64 tile_atb(const double *a, int aks, int ais, con
 }
 
 // two independent tiles at once: the loads and MFMA chains of both interleave
-template <int TS>
-__device__ __forceinline__ void tile_atb2(const double *a0, const double *b0, int b0ks, int b0js,
+__device__ __forceinline__ void tile_atb2_rt(const int TS, const double *a0, const double *b0, int b0ks, int b0js,
 	const double *a1, const double *b1, int b1ks, int b1js, int lane, v4f64 &d0, v4f64 &d1)
 {
 	d0 = (v4f64){0, 0, 0, 0};
@@ -63,8 +62,7 @@ __device__ __forceinline__ void tile_atb2(const double *a0, const double *b0, in
 //     c < j : W[i][c] -= f W[j][c]   (G update)      c == j: W[i][j] = -f   (new G entry)
 //     c >= i: W[i][c] -= f W[j][c]   (trailing update)
 // Writes R (upper) and G (strictly lower) into T, Dinv / G_JJ into the scratch tiles, 1/R_jj into dinv.
-template <int TS>
-__device__ __forceinline__ void diag_tile_factor(double *T, double *Dv, double *Gd, double *dinv, int j0,
+__device__ __forceinline__ void diag_tile_factor_rt(const int TS, double *T, double *Dv, double *Gd, double *dinv, int j0,
 	int lane, int *fail, int *info, int64_t k0)
 {
 	const int l15 = lane & 15, l4 = lane >> 4;
@@ -128,5 +126,19 @@ __device__ __forceinline__ void diag_tile_factor(double *T, double *Dv, double *
 	}
 }
 
+
+template <int TS>
+__device__ __forceinline__ void tile_atb2(const double *a0, const double *b0, int b0ks, int b0js,
+	const double *a1, const double *b1, int b1ks, int b1js, int lane, v4f64 &d0, v4f64 &d1)
+{
+	tile_atb2_rt(TS, a0, b0, b0ks, b0js, a1, b1, b1ks, b1js, lane, d0, d1);
+}
+
+template <int TS>
+__device__ __forceinline__ void diag_tile_factor(double *T, double *Dv, double *Gd, double *dinv, int j0,
+	int lane, int *fail, int *info, int64_t k0)
+{
+	diag_tile_factor_rt(TS, T, Dv, Gd, dinv, j0, lane, fail, info, k0);
+}
 
 } // namespace spp
