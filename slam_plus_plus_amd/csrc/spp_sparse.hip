@@ -705,7 +705,15 @@ void bigfront_extend_kernel(int s, int c, const int64_t *__restrict__ front_off,
 		F[padded(rl[i], w, pad) + (int64_t)padded(rl[j], w, pad) * ld] += Fc[(oc + i) + (int64_t)(oc + j) * ldc];
 }
 
-// forward substitution R^T y = b, leaves -> root. v = work vector of the front (length h).
+// ---- multifrontal triangular solves, blocked by 64 pivots, column-oriented (coalesced) -------------
+// forward  R^T y = b (leaves -> root):  per block  y_B = R_BB^-T v_B  (64-step substitution by one wave
+//          on an LDS copy of the 64 x 64 triangle), then  v_c -= R[B, c]^T y_B  for every later column c
+//          (each thread streams the 64 contiguous entries of its column).
+// backward R x = y (root -> leaves):    per block  t_B = v_B - sum_{c after B} R[B, c] x_c  (lane = row of
+//          the block: every column contributes 64 contiguous doubles), then x_B = R_BB^-1 t_B.
+// v = work vector of the front (length h, unpadded local indices) in HBM.
+constexpr int SB = 64;
+
 __global__ __launch_bounds__(FT)
 void front_fwd_kernel(const int32_t *__restrict__ level_fronts, const int64_t *__restrict__ front_off,
 	const int32_t *__restrict__ front_h, const int32_t *__restrict__ front_w, const int32_t *__restrict__ front_ld,
@@ -715,12 +723,14 @@ void front_fwd_kernel(const int32_t *__restrict__ level_fronts, const int64_t *_
 	const int32_t *__restrict__ rows, const double *__restrict__ fronts, double *__restrict__ vbuf,
 	double *__restrict__ xperm)
 {
+	__shared__ double tri[SB * (SB + 1)];
+	__shared__ double yb[SB];
 	const int s = level_fronts[blockIdx.x];
 	const int h = front_h[s], w = front_w[s], ld = front_ld[s], pad = front_pad[s];
 	const double *F = fronts + front_off[s];
 	double *v = vbuf + front_voff[s];
 	const int32_t *rw = rows + rows_ptr[s];
-	const int tid = threadIdx.x;
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	for(int c = tid; c < h; c += FT)
 		v[c] = (c < w) ? xperm[rw[c]] : 0.0;
 	__syncthreads();
@@ -733,20 +743,48 @@ void front_fwd_kernel(const int32_t *__restrict__ level_fronts, const int64_t *_
 			v[rl[i]] += vc[wc + i];
 		__syncthreads();
 	}
-	for(int j = 0; j < w; ++ j) {
-		const double yj = v[j] / F[j + (int64_t)j * ld];
-		__syncthreads(); // everyone has read v[j] before it is overwritten / used
-		if(tid == 0)
-			v[j] = yj;
-		for(int c = j + 1 + tid; c < h; c += FT)
-			v[c] -= F[j + (int64_t)padded(c, w, pad) * ld] * yj;
+	for(int j0 = 0; j0 < w; j0 += SB) {
+		const int nbk = (w - j0 < SB) ? (w - j0) : SB;
+		for(int e = tid; e < nbk * nbk; e += FT) {
+			const int i = e % nbk, k = e / nbk;
+			if(i <= k)
+				tri[i + k * (SB + 1)] = F[(j0 + i) + (int64_t)(j0 + k) * ld];
+		}
+		__syncthreads();
+		if(wave == 0) {
+			double b = (lane < nbk) ? v[j0 + lane] : 0.0;
+			for(int i = 0; i < nbk; ++ i) {
+				const double yi = __shfl(b, i) / tri[i + i * (SB + 1)];
+				if(lane == i)
+					b = yi;
+				else if(lane > i && lane < nbk)
+					b -= tri[i + lane * (SB + 1)] * yi;
+			}
+			if(lane < nbk) {
+				yb[lane] = b;
+				v[j0 + lane] = b;
+			}
+		}
+		__syncthreads();
+		for(int c = j0 + nbk + tid; c < h; c += FT) {
+			const double *col = F + j0 + (int64_t)padded(c, w, pad) * ld;
+			double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+			int i = 0;
+			for(; i + 8 <= nbk; i += 8) {
+#pragma unroll
+				for(int u = 0; u < 8; ++ u)
+					acc[u] += col[i + u] * yb[i + u];
+			}
+			for(; i < nbk; ++ i)
+				acc[0] += col[i] * yb[i];
+			v[c] -= ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+		}
 		__syncthreads();
 	}
 	for(int c = tid; c < w; c += FT)
 		xperm[rw[c]] = v[c];
 }
 
-// backward substitution R x = y, root -> leaves
 __global__ __launch_bounds__(FT)
 void front_bwd_kernel(const int32_t *__restrict__ level_fronts, const int64_t *__restrict__ front_off,
 	const int32_t *__restrict__ front_h, const int32_t *__restrict__ front_w, const int32_t *__restrict__ front_ld,
@@ -754,32 +792,62 @@ void front_bwd_kernel(const int32_t *__restrict__ level_fronts, const int64_t *_
 	const int64_t *__restrict__ front_voff, const int32_t *__restrict__ rows_ptr, const int32_t *__restrict__ rows,
 	const double *__restrict__ fronts, double *__restrict__ vbuf, double *__restrict__ xperm)
 {
+	__shared__ double tri[SB * (SB + 1)];
+	__shared__ double part[FT / 64][SB];
 	const int s = level_fronts[blockIdx.x];
 	const int h = front_h[s], w = front_w[s], ld = front_ld[s], pad = front_pad[s];
 	const double *F = fronts + front_off[s];
 	double *v = vbuf + front_voff[s];
 	const int32_t *rw = rows + rows_ptr[s];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	__shared__ double red[FT / 64];
 	for(int c = tid; c < h; c += FT)
 		v[c] = xperm[rw[c]]; // own part: y ; beyond: final x of the ancestors
 	__syncthreads();
-	for(int j = w; j > 0;) {
-		-- j;
-		double sum = 0;
-		for(int c = j + 1 + tid; c < h; c += FT)
-			sum += F[j + (int64_t)padded(c, w, pad) * ld] * v[c];
+	const int nblk = (w + SB - 1) / SB;
+	for(int bk = nblk; bk > 0;) {
+		-- bk;
+		const int j0 = bk * SB;
+		const int nbk = (w - j0 < SB) ? (w - j0) : SB;
+		for(int e = tid; e < nbk * nbk; e += FT) {
+			const int i = e % nbk, k = e / nbk;
+			if(i <= k)
+				tri[i + k * (SB + 1)] = F[(j0 + i) + (int64_t)(j0 + k) * ld];
+		}
+		// lane = row j0 + lane of the block; the waves split the columns after the block
+		{
+			double acc[4] = {0, 0, 0, 0};
+			const double *rowp = F + j0 + lane;
+			int c = j0 + nbk + wave * 4;
+			if(lane < nbk) {
+				for(; c + 4 <= h; c += 4 * (FT / 64)) {
 #pragma unroll
-		for(int off = 32; off > 0; off >>= 1)
-			sum += __shfl_xor(sum, off);
-		if(lane == 0)
-			red[wave] = sum;
+					for(int u = 0; u < 4; ++ u)
+						acc[u] += rowp[(int64_t)padded(c + u, w, pad) * ld] * v[c + u];
+				}
+				for(int u = 0; u < 4 && c + u < h; ++ u) // ragged last group (belongs to exactly one wave)
+					acc[0] += rowp[(int64_t)padded(c + u, w, pad) * ld] * v[c + u];
+			}
+			part[wave][lane] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+		}
 		__syncthreads();
-		if(tid == 0) {
+		if(wave == 0) {
 			double t = 0;
-			for(int q = 0; q < FT / 64; ++ q)
-				t += red[q];
-			v[j] = (v[j] - t) / F[j + (int64_t)j * ld];
+			if(lane < nbk) {
+				t = v[j0 + lane];
+#pragma unroll
+				for(int q = 0; q < FT / 64; ++ q)
+					t -= part[q][lane];
+			}
+			for(int i = nbk; i > 0;) {
+				-- i;
+				const double xi = __shfl(t, i) / tri[i + i * (SB + 1)];
+				if(lane == i)
+					t = xi;
+				else if(lane < i)
+					t -= tri[lane + i * (SB + 1)] * xi;
+			}
+			if(lane < nbk)
+				v[j0 + lane] = t;
 		}
 		__syncthreads();
 	}
