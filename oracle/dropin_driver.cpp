@@ -7,16 +7,26 @@
  * compared. Built by oracle/Makefile into oracle/_ref/dropin_driver (it contains reference code,
  * so it lives next to libspp_ref.so and never enters git).
  *
- * usage: dropin_driver [n_poses] [n_loop_closures]  ->  prints "max_abs_diff <d> iters <a> <b>"
+ * A second mode does the same for bundle adjustment with the reference's LEVENBERG-MARQUARDT solver
+ * (CNonlinearSolver_Lambda_LM, include/slam/NonlinearSolver_Lambda_LM.h:796-1160 -- what slam_app
+ * silently uses for every BA input, src/slam_app/Main.cpp:203-208): reference = UberBlock behind
+ * the reference's own CLinearSolver_Schur (-us), ours = CLinearSolver_HIP alone (it eliminates the
+ * landmarks itself on the GPU).
+ *
+ * usage: dropin_driver [n_poses] [n_loop_closures]     ->  "poses .. max_abs_diff <d> .."
+ *        dropin_driver ba [n_cams] [n_points]           ->  "ba cams .. max_abs_diff <d> .."
  */
 #include <stdio.h>
 #include <stdlib.h>
 #include <math.h>
+#include <string.h>
 #include <vector>
 
 #include "slam/LinearSolver_UberBlock.h"
 #include "slam/ConfigSolvers.h"
 #include "slam/SE2_Types.h"
+#include "slam/BA_Types.h"
+#include "slam/NonlinearSolver_Lambda_LM.h"
 #include "spp_adapter.h"
 
 typedef MakeTypelist(CVertexPose2D) TVertexTypelist;
@@ -89,8 +99,114 @@ static bool Run(const std::vector<TEdge> &r_edges, std::vector<double> &r_state,
 	return true;
 }
 
+// ---- bundle adjustment through the reference's LM solver -----------------------------------------
+typedef MakeTypelist_Safe((CVertexCam, CVertexXYZ)) TBAVertexTypelist;
+typedef MakeTypelist_Safe((CEdgeP2C3D)) TBAEdgeTypelist;
+typedef CFlatSystem<CBaseVertex, TBAVertexTypelist, CEdgeP2C3D, TBAEdgeTypelist> CBASystemType;
+
+struct TBAProblem {
+	std::vector<Eigen::Matrix<double, 11, 1> > cams; // initial estimates
+	std::vector<Eigen::Vector3d> points;
+	struct TObs { size_t n_cam, n_pt; Eigen::Vector2d z; };
+	std::vector<TObs> obs;
+};
+
+static void Generate_BA(size_t n_cams, size_t n_points, TBAProblem &r_p)
+{
+	std::vector<Eigen::Matrix<double, 6, 1> > true_cams(n_cams);
+	Eigen::Matrix<double, 5, 1> intr;
+	intr << 500, 500, 0, 0, 0;
+	for(size_t i = 0; i < n_cams; ++ i) {
+		double th = 6.283185307179586 * i / n_cams;
+		Eigen::Vector3d C(10 * cos(th), 10 * sin(th), 0.5 * sin(3 * th));
+		Eigen::Vector3d z = -C.normalized(), x = Eigen::Vector3d(0, 0, 1).cross(z).normalized(), y = z.cross(x);
+		Eigen::Matrix3d R;
+		R.row(0) = x; R.row(1) = y; R.row(2) = z; // world -> camera
+		Eigen::AngleAxisd aa(R);
+		true_cams[i].head<3>() = -R * C;
+		true_cams[i].tail<3>() = aa.axis() * aa.angle();
+		Eigen::Matrix<double, 11, 1> est;
+		est.head<6>() = true_cams[i];
+		for(int k = 0; k < 3; ++ k) {
+			est(k) += 0.02 * RandN();
+			est(3 + k) += 0.002 * RandN();
+		}
+		est.tail<5>() = intr;
+		r_p.cams.push_back(est);
+	}
+	for(size_t j = 0; j < n_points; ++ j) {
+		Eigen::Vector3d X(4 * Rand01() - 2, 4 * Rand01() - 2, 4 * Rand01() - 2);
+		size_t k = 3 + size_t(Rand01() * 4), c0 = size_t(Rand01() * n_cams);
+		for(size_t q = 0; q < k && q < n_cams; ++ q) {
+			size_t c = (c0 + q * (1 + n_cams / 9)) % n_cams;
+			Eigen::Vector2d z;
+			CBAJacobians::Project_P2C(true_cams[c], intr, X, z); // the reference's own camera model
+			TBAProblem::TObs o;
+			o.n_cam = c; o.n_pt = j;
+			o.z = z + Eigen::Vector2d(0.5 * RandN(), 0.5 * RandN());
+			r_p.obs.push_back(o);
+		}
+		r_p.points.push_back(X + Eigen::Vector3d(0.02 * RandN(), 0.02 * RandN(), 0.02 * RandN()));
+	}
+}
+
+template <class CLinearSolverType>
+static void Run_BA(const TBAProblem &r_p, bool b_use_schur, std::vector<double> &r_state, size_t n_max_iter)
+{
+	CBASystemType system;
+	CNonlinearSolver_Lambda_LM<CBASystemType, CLinearSolverType> solver(system, TIncrementalSolveSetting(),
+		TMarginalsComputationPolicy(), false, CLinearSolverType(), b_use_schur);
+	const size_t n_cams = r_p.cams.size();
+	for(size_t i = 0; i < n_cams; ++ i)
+		system.template r_Get_Vertex<CVertexCam>(i, r_p.cams[i]);
+	for(size_t j = 0; j < r_p.points.size(); ++ j)
+		system.template r_Get_Vertex<CVertexXYZ>(n_cams + j, r_p.points[j]);
+	for(size_t i = 0; i < r_p.obs.size(); ++ i)
+		system.r_Add_Edge(CEdgeP2C3D(n_cams + r_p.obs[i].n_pt, r_p.obs[i].n_cam, r_p.obs[i].z,
+			Eigen::Matrix2d::Identity(), system));
+	solver.Optimize(n_max_iter, 1e-9);
+	r_state.clear();
+	for(size_t i = 0, n = system.r_Vertex_Pool().n_Size(); i < n; ++ i) {
+		Eigen::VectorXd v = system.r_Vertex_Pool()[i].v_State();
+		for(int j = 0; j < v.rows(); ++ j)
+			r_state.push_back(v(j));
+	}
+}
+
+static int Compare(const char *p_s_what, size_t a, size_t b, const std::vector<double> &r_ref,
+	const std::vector<double> &r_hip, double f_tol)
+{
+	if(r_ref.size() != r_hip.size() || r_ref.empty())
+		return 3;
+	double f_max = 0, f_norm = 0;
+	for(size_t i = 0; i < r_ref.size(); ++ i) {
+		f_max = std::max(f_max, fabs(r_ref[i] - r_hip[i]));
+		f_norm = std::max(f_norm, fabs(r_ref[i]));
+	}
+	printf("%s %lu %lu max_abs_diff %.3e max_abs_state %.3e\n", p_s_what, (unsigned long)a, (unsigned long)b, f_max, f_norm);
+	return (f_max <= f_tol * std::max(1.0, f_norm))? 0 : 1;
+}
+
 int main(int n_arg_num, const char **p_arg_list)
 {
+	if(n_arg_num > 1 && !strcmp(p_arg_list[1], "ba")) {
+		size_t n_cams = (n_arg_num > 2)? atol(p_arg_list[2]) : 12;
+		size_t n_points = (n_arg_num > 3)? atol(p_arg_list[3]) : 300;
+		size_t n_iters = (n_arg_num > 4)? atol(p_arg_list[4]) : 2;
+		// BA keeps a gauge freedom (scale) that only the LM damping controls: after many iterations two
+		// solvers drift apart along it, so the comparison is made after a few LM iterations
+		TBAProblem problem;
+		Generate_BA(n_cams, n_points, problem);
+		std::vector<double> ref_state, hip_state;
+		try {
+			Run_BA<CLinearSolver_UberBlock<CBASystemType::_TyHessianMatrixBlockList> >(problem, true, ref_state, n_iters);
+			Run_BA<CLinearSolver_HIP>(problem, false, hip_state, n_iters);
+		} catch(std::exception &r_exc) {
+			fprintf(stderr, "error: %s\n", r_exc.what());
+			return 2;
+		}
+		return Compare("ba cams/points", n_cams, n_points, ref_state, hip_state, 1e-7);
+	}
 	size_t n_poses = (n_arg_num > 1)? atol(p_arg_list[1]) : 400;
 	size_t n_loops = (n_arg_num > 2)? atol(p_arg_list[2]) : 200;
 	std::vector<TEdge> edges;

@@ -35,13 +35,16 @@ def pytest_sessionstart(session):
         return
     ref_dir = os.path.join(ROOT, "oracle", "_ref")
     env = dict(os.environ, OMP_NUM_THREADS="1")
-    for name, args in (("dropin_driver", ["400", "200"]), ("slam_simple_hip", [])):
+    for key, name, args in (("dropin_driver", "dropin_driver", ["400", "200"]),
+                            ("dropin_driver_ba", "dropin_driver", ["ba", "16", "600", "1"]),
+                            ("dropin_driver_ba3", "dropin_driver", ["ba", "40", "3000", "3"]),
+                            ("slam_simple_hip", "slam_simple_hip", [])):
         exe = os.path.join(ref_dir, name)
         if not os.path.exists(exe):
             continue
         with tempfile.TemporaryDirectory() as tmp:
             try:
                 p = subprocess.run([exe] + args, cwd=tmp, env=env, capture_output=True, text=True, timeout=300)
-                DROPIN_RESULTS[name] = (p.returncode, p.stdout, p.stderr, sorted(os.listdir(tmp)))
+                DROPIN_RESULTS[key] = (p.returncode, p.stdout, p.stderr, sorted(os.listdir(tmp)))
             except Exception as e:  # noqa: BLE001
-                DROPIN_RESULTS[name] = (-999, "", repr(e), [])
+                DROPIN_RESULTS[key] = (-999, "", repr(e), [])
