@@ -233,4 +233,55 @@ int ref_factor_fill(void *h, int64_t *out_nnzb, int64_t *out_nnz)
 	}
 }
 
+/* Interchange check for slam_plus_plus_amd/formats.py: the REFERENCE loads a system.mtx / system.bla
+ * pair (CUberBlockMatrix::Load_MatrixMarket, BlockMatrix.cpp:11589-12060), takes a deep upper view
+ * and solves it with CLinearSolver_UberBlock (3x3 blocks when problem == 0, 6x6 when 1, BA otherwise).
+ * out_dims[0..1] receive (n, number of stored upper blocks). */
+int ref_solve_files(const char *p_s_mtx, const char *p_s_bla, int problem, double *rhs, int64_t n_rhs,
+	int64_t *out_dims)
+{
+	try {
+		CUberBlockMatrix full, upper;
+		if(!full.Load_MatrixMarket(p_s_mtx, p_s_bla))
+			return -1;
+		upper.TriangularViewOf(full, true, false); // deep copy: a shared view dangles when `full` dies
+		if(int64_t(upper.n_Column_Num()) != n_rhs)
+			return -2;
+		out_dims[0] = int64_t(upper.n_Column_Num());
+		out_dims[1] = int64_t(upper.n_Block_Num());
+		Eigen::VectorXd eta = Eigen::Map<const Eigen::VectorXd>(rhs, n_rhs);
+		bool ok;
+		if(problem == 0) {
+			CUber_SE2 s;
+			ok = s.Solve_PosDef_Blocky(upper, eta);
+		} else if(problem == 1) {
+			CUber_SE3 s;
+			ok = s.Solve_PosDef_Blocky(upper, eta);
+		} else {
+			CUber_BA s;
+			ok = s.Solve_PosDef_Blocky(upper, eta);
+		}
+		if(!ok)
+			return 1;
+		memcpy(rhs, eta.data(), n_rhs * sizeof(double));
+		return 0;
+	} catch(std::exception &) {
+		return -3;
+	}
+}
+
+/* the reference WRITES its own dump (Save_MatrixMarket 'U' + Save_BlockLayout) of the current Lambda */
+int ref_save_files(void *h, const double *vals, const int64_t *blk_off, const char *p_s_mtx, const char *p_s_bla)
+{
+	TRef &r = *(TRef*)h;
+	try {
+		for(int64_t j = 0; j < r.nb; ++ j)
+			for(int64_t p = r.col_ptr[j]; p < r.col_ptr[j + 1]; ++ p)
+				memcpy(r.blk_ptr[p], vals + blk_off[p], size_t(r.dim[r.row_idx[p]]) * size_t(r.dim[j]) * sizeof(double));
+		return r.lambda.Save_MatrixMarket(p_s_mtx, p_s_bla, "lambda", "matrix coordinate real symmetric", 'U')? 0 : -1;
+	} catch(std::exception &) {
+		return -2;
+	}
+}
+
 } // extern "C"

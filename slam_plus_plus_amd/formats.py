@@ -1,0 +1,195 @@
+"""File formats on either side of the hot path, so that fixtures are interchangeable with
+the reference and real datasets can be ingested the moment they are supplied.
+
+* MatrixMarket + block layout pair written by `slam_plus_plus -dsm` (system.mtx / system.bla):
+  reference writer src/slam/BlockMatrix.cpp:12063-12205 (Save_BlockLayout, Save_MatrixMarket), reader
+  :11589,11682-12060. `.bla` = "rows x cols (nnz)" / "brows x bcols (nblocks)" / row bases + total /
+  column bases + total. A symmetric dump lists the stored UPPER triangle as lower-triangle coordinates
+  (col+1, row+1, value), values printed with %.15g / %.15f.
+* SLAM++ / g2o-style text graphs: the token set of include/slam_app/ParsePrimitives.h:75-1665 that
+  the five BASELINE.json configs use (2D poses, 3D poses, BA cameras / points / projections).
+  Geometry (Jacobian evaluation) stays with the reference; for 2D pose graphs `se2_linearize`
+  provides the analytic Jacobians so that a graph file can be turned into hot-path inputs.
+"""
+import numpy as np
+
+from .blockcsc import BlockCSC, structure_from_pairs
+
+
+# --------------------------------------------------------------------------------------------------
+# system.mtx / system.bla
+# --------------------------------------------------------------------------------------------------
+def save_matrix_market(path_mtx, path_bla, lam, kind="lambda"):
+    """Write Lambda (upper block triangle) the way CUberBlockMatrix::Save_MatrixMarket(..., 'U') does."""
+    di = lam.dim[lam.row_idx].astype(np.int64)
+    dj = lam.dim[lam.col_idx].astype(np.int64)
+    rows, cols, vals = [], [], []
+    for p in range(lam.nnzb):
+        i, j = int(lam.row_idx[p]), int(lam.col_idx[p])
+        blk = lam.vals[lam.blk_off[p]:lam.blk_off[p] + di[p] * dj[p]].reshape(dj[p], di[p]).T
+        r = lam.base[i] + np.arange(di[p])[:, None]
+        c = lam.base[j] + np.arange(dj[p])[None, :]
+        keep = (c >= r)
+        rows.append(np.broadcast_to(r, blk.shape)[keep])
+        cols.append(np.broadcast_to(c, blk.shape)[keep])
+        vals.append(blk[keep])
+    rows, cols, vals = np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
+    with open(path_mtx, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real symmetric\n")
+        f.write("%-------------------------------------------------------------------------------\n")
+        f.write("% UberBlockMatrix matrix dump\n% kind: " + kind + "\n")
+        f.write("%-------------------------------------------------------------------------------\n")
+        f.write("%d %d %d\n" % (lam.n, lam.n, vals.size))
+        for r, c, v in zip(rows, cols, vals):  # lower-triangle coordinates: (col + 1, row + 1)
+            f.write(("%d %d %.15f\n" if abs(v) > 1 else "%d %d %.15g\n") % (c + 1, r + 1, v))
+    with open(path_bla, "w") as f:
+        f.write("%d x %d (%d)\n" % (lam.n, lam.n, int((di * dj).sum())))
+        f.write("%d x %d (%d)\n" % (lam.nb, lam.nb, lam.nnzb))
+        f.write(" ".join(str(int(b)) for b in lam.base) + "\n")
+        f.write(" ".join(str(int(b)) for b in lam.base) + "\n")
+
+
+def load_block_layout(path_bla):
+    with open(path_bla) as f:
+        lines = [ln.strip() for ln in f if ln.strip()]
+    n = int(lines[0].split()[0])
+    nb = int(lines[1].split()[0])
+    base = np.array(lines[2].split(), dtype=np.int64)
+    assert base.size == nb + 1 and base[-1] == n and base[0] == 0
+    return n, nb, base
+
+
+def load_matrix_market(path_mtx, path_bla):
+    """Read a (symmetric or general) MatrixMarket file plus its block layout into an upper BlockCSC.
+    Entries below the diagonal of a general file are ignored; every block that holds at least one
+    entry is materialized fully (missing entries are zero), diagonal blocks are mirrored."""
+    n, nb, base = load_block_layout(path_bla)
+    dim = np.diff(base).astype(np.int32)
+    rr, cc, vv = [], [], []
+    symmetric = False
+    with open(path_mtx) as f:
+        header = None
+        for ln in f:
+            if ln.startswith("%%MatrixMarket"):
+                symmetric = "symmetric" in ln
+                continue
+            if ln.startswith("%") or not ln.strip():
+                continue
+            if header is None:
+                header = ln.split()
+                assert int(header[0]) == n and int(header[1]) == n
+                continue
+            a, b, v = ln.split()
+            rr.append(int(a) - 1)
+            cc.append(int(b) - 1)
+            vv.append(float(v))
+    rr, cc, vv = np.array(rr, dtype=np.int64), np.array(cc, dtype=np.int64), np.array(vv)
+    if symmetric:  # stored as lower-triangle coordinates: flip into the upper triangle
+        lo = rr > cc
+        rr, cc = np.where(lo, cc, rr), np.where(lo, rr, cc)
+    keep = rr <= cc
+    rr, cc, vv = rr[keep], cc[keep], vv[keep]
+    brow = np.searchsorted(base, rr, side="right") - 1
+    bcol = np.searchsorted(base, cc, side="right") - 1
+    st, blk, _ = structure_from_pairs(dim, brow, bcol)
+    vals = np.zeros(st.nvals)
+    di = dim[brow].astype(np.int64)
+    pos = st.blk_off[blk] + (rr - base[brow]) + (cc - base[bcol]) * di
+    vals[pos] = vv
+    # mirror the diagonal blocks (the reference stores them fully symmetric)
+    dsel = brow == bcol
+    pos_t = st.blk_off[blk[dsel]] + (cc[dsel] - base[bcol[dsel]]) + (rr[dsel] - base[brow[dsel]]) * di[dsel]
+    vals[pos_t] = vv[dsel]
+    return st.with_vals(vals)
+
+
+# --------------------------------------------------------------------------------------------------
+# text graphs
+# --------------------------------------------------------------------------------------------------
+_SE2_EDGE = {"EDGE_SE2", "EDGE2", "EDGE", "ODOMETRY"}
+_SE2_VERTEX = {"VERTEX_SE2", "VERTEX2", "VERTEX"}
+_SE3_EDGE = {"EDGE3", "EDGE_SE3"}
+_SE3_VERTEX = {"VERTEX3", "VERTEX_SE3"}
+
+
+def _upper_to_full(u, d):
+    m = np.zeros((d, d))
+    m[np.triu_indices(d)] = u
+    return m + np.triu(m, 1).T
+
+
+def load_graph(path):
+    """Parse the tokens the BASELINE configs use. Returns a dict of numpy arrays:
+      se2_vertices (id, x, y, theta), se2_edges (i, j, dx, dy, dtheta) + se2_info (3x3 each)
+      se3_vertices (id, 6), se3_edges (i, j, 6) + se3_info (6x6 each)
+      cams (id, 6 pose + 5 intrinsics), points (id, xyz), projections (point id, cam id, u, v) + proj_info (2x2)
+    2D information is given as the 6 upper-triangular values in the order of
+    ParsePrimitives.h (xx xy yy tt xt yt for the classic EDGE2 format is NOT assumed: the g2o
+    EDGE_SE2 order xx xy xt yy yt tt is)."""
+    out = {k: [] for k in ("se2_vertices", "se2_edges", "se2_info", "se3_vertices", "se3_edges", "se3_info",
+                           "cams", "points", "projections", "proj_info")}
+    with open(path) as f:
+        for ln in f:
+            t = ln.split()
+            if not t or t[0].startswith("#") or t[0].startswith("%"):
+                continue
+            tok, a = t[0].upper(), t[1:]
+            if tok in _SE2_VERTEX and len(a) >= 4:
+                out["se2_vertices"].append([float(x) for x in a[:4]])
+            elif tok in _SE2_EDGE and len(a) >= 11:
+                out["se2_edges"].append([float(x) for x in a[:5]])
+                out["se2_info"].append(_upper_to_full([float(x) for x in a[5:11]], 3))
+            elif tok in _SE3_VERTEX and len(a) >= 7:
+                out["se3_vertices"].append([float(x) for x in a[:7]])
+            elif tok in _SE3_EDGE and len(a) >= 29:
+                out["se3_edges"].append([float(x) for x in a[:8]])
+                out["se3_info"].append(_upper_to_full([float(x) for x in a[8:29]], 6))
+            elif tok == "VERTEX_CAM" and len(a) >= 13:
+                out["cams"].append([float(x) for x in a[:13]])
+            elif tok == "VERTEX_XYZ" and len(a) >= 4:
+                out["points"].append([float(x) for x in a[:4]])
+            elif tok in ("EDGE_PROJECT_P2MC", "EDGE_PROJECT_P2C") and len(a) >= 7:
+                out["projections"].append([float(x) for x in a[:4]])
+                out["proj_info"].append(_upper_to_full([float(x) for x in a[4:7]], 2))
+            # CONSISTENCY_MARKER and unknown tokens are skipped (batch mode ignores them)
+    return {k: np.array(v) for k, v in out.items()}
+
+
+def save_se2_graph(path, poses, edges, info):
+    """poses: (n, 3) x y theta; edges: (m, 5) i j dx dy dtheta; info: (m, 3, 3)"""
+    with open(path, "w") as f:
+        for i, p in enumerate(poses):
+            f.write("VERTEX_SE2 %d %.17g %.17g %.17g\n" % (i, p[0], p[1], p[2]))
+        iu = np.triu_indices(3)
+        for e, m in zip(edges, info):
+            f.write("EDGE_SE2 %d %d %.17g %.17g %.17g " % (int(e[0]), int(e[1]), e[2], e[3], e[4]))
+            f.write(" ".join("%.17g" % x for x in m[iu]) + "\n")
+
+
+def se2_linearize(poses, edges, info):
+    """Hot-path inputs (synth.Problem) of a 2D pose graph at the given estimate: analytic Jacobians of
+    the relative-pose error (the quantity reference include/slam/2DSolverBase.h:269-373 computes),
+    residual = measurement - prediction with the angle wrapped to (-pi, pi]."""
+    from .synth import Problem
+    poses = np.asarray(poses, dtype=np.float64)
+    edges = np.asarray(edges, dtype=np.float64)
+    v0 = edges[:, 0].astype(np.int64)
+    v1 = edges[:, 1].astype(np.int64)
+    ne = v0.size
+    c, s = np.cos(poses[v0, 2]), np.sin(poses[v0, 2])
+    d = poses[v1, :2] - poses[v0, :2]
+    J0 = np.zeros((ne, 3, 3))
+    J1 = np.zeros((ne, 3, 3))
+    J0[:, 0, 0], J0[:, 0, 1], J0[:, 0, 2] = -c, -s, -s * d[:, 0] + c * d[:, 1]
+    J0[:, 1, 0], J0[:, 1, 1], J0[:, 1, 2] = s, -c, -c * d[:, 0] - s * d[:, 1]
+    J0[:, 2, 2] = -1
+    J1[:, 0, 0], J1[:, 0, 1] = c, s
+    J1[:, 1, 0], J1[:, 1, 1] = -s, c
+    J1[:, 2, 2] = 1
+    pred = np.stack([c * d[:, 0] + s * d[:, 1], -s * d[:, 0] + c * d[:, 1], poses[v1, 2] - poses[v0, 2]], axis=1)
+    r = edges[:, 2:5] - pred
+    r[:, 2] = (r[:, 2] + np.pi) % (2 * np.pi) - np.pi
+    return Problem(name="se2_graph", dim=np.full(poses.shape[0], 3, dtype=np.int32), v0=v0, v1=v1, d0=3, d1=3, rd=3,
+                   J0=np.ascontiguousarray(J0.transpose(0, 2, 1)).reshape(ne, 9),
+                   J1=np.ascontiguousarray(J1.transpose(0, 2, 1)).reshape(ne, 9),
+                   Om=np.asarray(info, dtype=np.float64).reshape(ne, 9), r=r, unary_vertex=int(v0[0]), damping=0.0)

@@ -1,0 +1,99 @@
+"""File formats either side of the hot path: the MatrixMarket + block-layout pair that
+`slam_plus_plus -dsm` dumps, and the text graph tokens. Interchange with the reference is checked
+both ways when oracle/_ref is present: the reference solves a file pair WE wrote, and we read a pair
+the REFERENCE wrote."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from slam_plus_plus_amd import formats, synth
+from oracle import spp_oracle as orc
+
+
+def _rel(a, b):
+    return np.linalg.norm(a - b) / np.linalg.norm(b)
+
+
+@pytest.mark.parametrize("name", ["se2_small", "se3_small", "ba_tiny"])
+def test_mtx_bla_roundtrip(tmp_path, name):
+    lam, eta = orc.assemble(synth.make(name))
+    mtx, bla = str(tmp_path / "system.mtx"), str(tmp_path / "system.bla")
+    formats.save_matrix_market(mtx, bla, lam)
+    back = formats.load_matrix_market(mtx, bla)
+    assert np.array_equal(back.dim, lam.dim)
+    assert np.array_equal(back.col_ptr, lam.col_ptr) and np.array_equal(back.row_idx, lam.row_idx)
+    assert np.abs(back.vals - lam.vals).max() <= 1e-14 * np.abs(lam.vals).max()  # %.15g text
+
+
+@pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("name,problem", [("se2_small", 0), ("se3_small", 1), ("ba_tiny", 2)])
+def test_reference_reads_our_files_and_we_read_its_files(tmp_path, name, problem):
+    lam, eta = orc.assemble(synth.make(name), damping=10.0)  # well conditioned: text I/O costs 1e-15
+    R = orc.ref()
+    # (1) we write, the reference reads + solves
+    mtx, bla = str(tmp_path / "ours.mtx"), str(tmp_path / "ours.bla")
+    formats.save_matrix_market(mtx, bla, lam)
+    x = eta.copy()
+    dims = (ctypes.c_int64 * 2)()
+    R.ref_solve_files.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+    st = R.ref_solve_files(mtx.encode(), bla.encode(), problem, x.ctypes.data, lam.n, dims)
+    assert st == 0 and dims[0] == lam.n and dims[1] == lam.nnzb
+    st, xr, _ = orc.RefSolver("uberblock", lam).solve(lam.vals, eta)
+    assert _rel(x, xr) < 1e-10
+    # (2) the reference writes, we read
+    rs = orc.RefSolver("uberblock", lam)
+    mtx2, bla2 = str(tmp_path / "ref.mtx"), str(tmp_path / "ref.bla")
+    R.ref_save_files.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p]
+    assert R.ref_save_files(rs.h, lam.vals.ctypes.data, lam.blk_off.ctypes.data, mtx2.encode(), bla2.encode()) == 0
+    back = formats.load_matrix_market(mtx2, bla2)
+    assert np.array_equal(back.row_idx, lam.row_idx) and np.array_equal(back.dim, lam.dim)
+    assert np.abs(back.vals - lam.vals).max() <= 1e-14 * np.abs(lam.vals).max()
+
+
+def test_text_graph_tokens(tmp_path):
+    p = tmp_path / "g.txt"
+    p.write_text("\n".join([
+        "# comment",
+        "VERTEX_SE2 0 0 0 0", "VERTEX_SE2 1 1.0 0.1 0.05",
+        "EDGE_SE2 0 1 1.03 0.01 -0.01 1111.11 0 0 1111.11 0 10000",
+        "VERTEX_CAM 0 0.1 0.2 0.3 0 0 0 1 500 500 0 0 0",
+        "VERTEX_XYZ 1 1.5 -0.5 7",
+        "EDGE_PROJECT_P2MC 1 0 12.5 -3.25 1 0 1",
+        "CONSISTENCY_MARKER",
+        "EDGE3 0 1 1 0 0 0 0 0.1 " + " ".join(["1"] * 21),
+    ]))
+    g = formats.load_graph(str(p))
+    assert g["se2_vertices"].shape == (2, 4) and g["se2_edges"].shape == (1, 5)
+    assert np.allclose(g["se2_info"][0], np.diag([1111.11, 1111.11, 10000]))
+    assert g["cams"].shape == (1, 13) and g["points"].shape == (1, 4)
+    assert g["projections"].tolist() == [[1, 0, 12.5, -3.25]] and np.allclose(g["proj_info"][0], np.eye(2))
+    assert g["se3_edges"].shape == (1, 8) and g["se3_info"][0].shape == (6, 6)
+
+
+def test_se2_graph_file_to_hot_path_inputs(tmp_path):
+    """write a pose graph, read it back, linearize: Lambda / eta equal those of the same graph built
+    in memory (the reader + linearization feed the assembly path)"""
+    rng = np.random.default_rng(5)
+    n = 60
+    poses = np.cumsum(rng.normal(0.5, 0.2, size=(n, 3)) * [1, 1, 0.1], axis=0)
+    i = np.arange(n - 1)
+    extra = np.stack([rng.integers(0, n - 5, 15), rng.integers(5, n, 15)], axis=1)
+    extra = extra[extra[:, 0] != extra[:, 1]]
+    ij = np.concatenate([np.stack([i, i + 1], axis=1), extra])
+    meas = rng.normal(0, 0.3, size=(ij.shape[0], 3))
+    edges = np.concatenate([ij.astype(float), meas], axis=1)
+    info = np.tile(np.diag([100.0, 100.0, 400.0]), (ij.shape[0], 1, 1))
+    path = str(tmp_path / "graph.txt")
+    formats.save_se2_graph(path, poses, edges, info)
+    g = formats.load_graph(path)
+    prob_file = formats.se2_linearize(g["se2_vertices"][:, 1:], g["se2_edges"], g["se2_info"])
+    prob_mem = formats.se2_linearize(poses, edges, info)
+    lam_f, eta_f = orc.assemble(prob_file)
+    lam_m, eta_m = orc.assemble(prob_mem)
+    assert np.array_equal(lam_f.row_idx, lam_m.row_idx)
+    assert np.abs(lam_f.vals - lam_m.vals).max() <= 1e-12 * np.abs(lam_m.vals).max()
+    assert np.abs(eta_f - eta_m).max() <= 1e-12 * np.abs(eta_m).max()
+    st, x = orc.solve_blocky(lam_f, eta_f)
+    assert st == 0 and np.all(np.isfinite(x))
