@@ -30,6 +30,7 @@
 #include "spp_internal.h"
 #include "spp_tiles.h"
 #include <stdlib.h>
+#include <algorithm>
 
 namespace spp {
 
@@ -41,22 +42,26 @@ constexpr int LDS_STRIDE = 18;   // doubles per tile column in LDS: conflict-fre
 // C (M x N) {-=, =} A^T B,  A: K x M (lda), B: K x N (ldb), K % 16 == 0. Column-major.
 // MODE 0: C -= A^T B (trailing update);  MODE 1: C = A^T B (may alias B when BM covers all rows).
 // --------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int MODE>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64)
+// MINW = waves per SIMD the register allocator must leave room for (2nd argument of
+// __launch_bounds__): 2 for the 512-thread configuration = one workgroup per CU and a 256-VGPR budget
+// (at the default budget of 128 the staging registers were spilled to scratch inside the k-loop)
+template <int BM, int BN, int WM, int WN, int MODE, int DEPTH = 2, int MINW = 1, int BKT = 16>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_waves_per_eu(MINW == 2 ? 2 : 1, MINW == 2 ? 2 : 8)))
 void gemm_tn_kernel(int64_t M, int64_t N, int K, const double *__restrict__ A, int64_t lda,
 	const double *B, int64_t ldb, double *C, int64_t ldc, int upper_only)
 {
 	constexpr int NWM = BM / WM, NWN = BN / WN, NT = NWM * NWN * 64;
 	constexpr int TA = WM / 16, TB = WN / 16;       // MFMA tiles per wave
-	constexpr int PA = (BM * 8) / NT, PB = (BN * 8) / NT; // 16-byte pieces per thread per slab
-	static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "tile/threads mismatch");
+	constexpr int PPC = BKT / 2, LSTR = BKT + 2;            // 16-byte pieces per column, LDS column stride
+	constexpr int PA = (BM * PPC) / NT, PB = (BN * PPC) / NT; // pieces per thread per slab
+	static_assert((BM * PPC) % NT == 0 && (BN * PPC) % NT == 0, "tile/threads mismatch");
 
 	const int64_t m0 = (int64_t)blockIdx.x * BM, n0 = (int64_t)blockIdx.y * BN;
 	if(upper_only && m0 >= n0 + BN)
 		return; // tile strictly below the diagonal
 
-	__shared__ double As[BM * LDS_STRIDE];
-	__shared__ double Bs[BN * LDS_STRIDE];
+	extern __shared__ double gemm_lds[];
+	double *As = gemm_lds, *Bs = gemm_lds + BM * LSTR;
 
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int wm = (wave % NWM) * WM, wn = (wave / NWM) * WN;
@@ -82,61 +87,75 @@ void gemm_tn_kernel(int64_t M, int64_t N, int K, const double *__restrict__ A, i
 		}
 
 	// global staging: piece p -> (column p / 8, 16-byte piece p % 8); two slabs in flight
-	double2 ra[2][PA], rb[2][PB];
-	const double *pa[PA], *pb[PB];
+	double2 ra0[PA], ra1[PA], rb0[PB], rb1[PB];
+	uint32_t pa[PA], pb[PB]; // element offsets (32-bit: fewer VGPRs than pointers)
 #pragma unroll
 	for(int i = 0; i < PA; ++ i) {
 		int p = tid + i * NT;
-		int64_t col = m0 + (p >> 3);
+		int64_t col = m0 + (p / PPC);
 		if(col > M - 1) col = M - 1; // clamp: computes garbage that is never stored
-		pa[i] = A + col * lda + (p & 7) * 2;
+		pa[i] = (uint32_t)(col * lda + (p % PPC) * 2);
 	}
 #pragma unroll
 	for(int i = 0; i < PB; ++ i) {
 		int p = tid + i * NT;
-		int64_t col = n0 + (p >> 3);
+		int64_t col = n0 + (p / PPC);
 		if(col > N - 1) col = N - 1;
-		pb[i] = B + col * ldb + (p & 7) * 2;
+		pb[i] = (uint32_t)(col * ldb + (p % PPC) * 2);
 	}
 #define SPP_LOAD_SLAB(buf, kofs) \
-	_Pragma("unroll") for(int i = 0; i < PA; ++ i) ra[buf][i] = *(const double2*)(pa[i] + (kofs)); \
-	_Pragma("unroll") for(int i = 0; i < PB; ++ i) rb[buf][i] = *(const double2*)(pb[i] + (kofs));
+	_Pragma("unroll") for(int i = 0; i < PA; ++ i) (buf ? ra1 : ra0)[i] = *(const double2*)(A + (size_t)pa[i] + (kofs)); \
+	_Pragma("unroll") for(int i = 0; i < PB; ++ i) (buf ? rb1 : rb0)[i] = *(const double2*)(B + (size_t)pb[i] + (kofs));
 #define SPP_STORE_SLAB(buf) \
 	_Pragma("unroll") for(int i = 0; i < PA; ++ i) { int p = tid + i * NT; \
-		*(double2*)(&As[(p >> 3) * LDS_STRIDE + (p & 7) * 2]) = ra[buf][i]; } \
+		*(double2*)(&As[(p / PPC) * LSTR + (p % PPC) * 2]) = (buf ? ra1 : ra0)[i]; } \
 	_Pragma("unroll") for(int i = 0; i < PB; ++ i) { int p = tid + i * NT; \
-		*(double2*)(&Bs[(p >> 3) * LDS_STRIDE + (p & 7) * 2]) = rb[buf][i]; }
+		*(double2*)(&Bs[(p / PPC) * LSTR + (p % PPC) * 2]) = (buf ? rb1 : rb0)[i]; }
 #define SPP_COMPUTE_SLAB() \
-	_Pragma("unroll") for(int kk = 0; kk < BK / 4; ++ kk) { \
+	_Pragma("unroll") for(int kk = 0; kk < BKT / 4; ++ kk) { \
 		double fa[TA], fb[TB]; \
-		_Pragma("unroll") for(int a = 0; a < TA; ++ a) fa[a] = As[(wm + a * 16 + l15) * LDS_STRIDE + kk * 4 + l4]; \
-		_Pragma("unroll") for(int b = 0; b < TB; ++ b) fb[b] = Bs[(wn + b * 16 + l15) * LDS_STRIDE + kk * 4 + l4]; \
+		_Pragma("unroll") for(int a = 0; a < TA; ++ a) fa[a] = As[(wm + a * 16 + l15) * LSTR + kk * 4 + l4]; \
+		_Pragma("unroll") for(int b = 0; b < TB; ++ b) fb[b] = Bs[(wn + b * 16 + l15) * LSTR + kk * 4 + l4]; \
 		_Pragma("unroll") for(int b = 0; b < TB; ++ b) \
 			_Pragma("unroll") for(int a = 0; a < TA; ++ a) \
 				acc[b][a] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[b], fa[a], acc[b][a], 0, 0, 0); \
 	}
 
-	SPP_LOAD_SLAB(0, 0)
-	if(BK < K) {
-		SPP_LOAD_SLAB(1, BK)
-	}
-	for(int k0 = 0; k0 < K; k0 += 2 * BK) {
-		__syncthreads(); // previous slab fully consumed
-		SPP_STORE_SLAB(0)
-		__syncthreads();
-		if(k0 + 2 * BK < K) {
-			SPP_LOAD_SLAB(0, k0 + 2 * BK)
-		}
-		SPP_COMPUTE_SLAB()
-		if(k0 + BK < K) {
+	if(DEPTH == 1) {
+		// one slab in flight (fewer staging registers: no scratch at 128 VGPRs, two workgroups per CU)
+		SPP_LOAD_SLAB(0, 0)
+		for(int k0 = 0; k0 < K; k0 += BKT) {
 			__syncthreads();
-			SPP_STORE_SLAB(1)
+			SPP_STORE_SLAB(0)
 			__syncthreads();
-			if(k0 + 3 * BK < K) {
-				SPP_LOAD_SLAB(1, k0 + 3 * BK)
+			if(k0 + BKT < K) {
+				SPP_LOAD_SLAB(0, k0 + BKT)
 			}
 			SPP_COMPUTE_SLAB()
 		}
+	} else {
+	SPP_LOAD_SLAB(0, 0)
+	if(BKT < K) {
+		SPP_LOAD_SLAB(1, BKT)
+	}
+	for(int k0 = 0; k0 < K; k0 += 2 * BKT) {
+		__syncthreads(); // previous slab fully consumed
+		SPP_STORE_SLAB(0)
+		__syncthreads();
+		if(k0 + 2 * BKT < K) {
+			SPP_LOAD_SLAB(0, k0 + 2 * BKT)
+		}
+		SPP_COMPUTE_SLAB()
+		if(k0 + BKT < K) {
+			__syncthreads();
+			SPP_STORE_SLAB(1)
+			__syncthreads();
+			if(k0 + 3 * BKT < K) {
+				SPP_LOAD_SLAB(1, k0 + 3 * BKT)
+			}
+			SPP_COMPUTE_SLAB()
+		}
+	}
 	}
 #undef SPP_LOAD_SLAB
 #undef SPP_STORE_SLAB
@@ -159,7 +178,7 @@ void gemm_tn_kernel(int64_t M, int64_t N, int K, const double *__restrict__ A, i
 		}
 }
 
-template <int BM, int BN, int WM, int WN, int MODE>
+template <int BM, int BN, int WM, int WN, int MODE, int DEPTH = 2, int MINW = 1, int BKT = 16>
 static void launch_gemm(hipStream_t s, int64_t M, int64_t N, int K, const double *A, int64_t lda,
 	const double *B, int64_t ldb, double *C, int64_t ldc, bool upper_only)
 {
@@ -167,7 +186,15 @@ static void launch_gemm(hipStream_t s, int64_t M, int64_t N, int K, const double
 	dim3 block((BM / WM) * (BN / WN) * 64);
 	if(!grid.x || !grid.y)
 		return;
-	hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, WM, WN, MODE>), grid, block, 0, s,
+	const size_t lds = (size_t)(BM + BN) * (BKT + 2) * sizeof(double);
+	static bool attr = false;
+	if(!attr && lds > 65536) {
+		SPP_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tn_kernel<BM, BN, WM, WN, MODE, DEPTH, MINW, BKT>,
+			hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		attr = true;
+	}
+	SPP_REQUIRE(K % BKT == 0, SPP_E_BADARG, "gemm: K must be a multiple of the slab depth");
+	hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, WM, WN, MODE, DEPTH, MINW, BKT>), grid, block, lds, s,
 		M, N, K, A, lda, B, ldb, C, ldc, upper_only ? 1 : 0);
 }
 
@@ -304,10 +331,26 @@ void dense_gemm_tn_sub(spp_ctx *ctx, int64_t m, int64_t n, int64_t k, const doub
 	static int cfg = -1;
 	if(cfg < 0) {
 		const char *e = getenv("SPP_GEMM_CFG");
-		cfg = e ? atoi(e) : 1;
+		cfg = e ? atoi(e) : 9;
 	}
 	if(t128 >= 192 && cfg == 1)
-		launch_gemm<128, 128, 64, 32, 0>(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc, upper_only);
+		launch_gemm<128, 128, 64, 32, 0, 1>(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc, upper_only);
+	else if(t128 >= 192 && cfg == 4)
+		launch_gemm<128, 128, 64, 32, 0, 2, 2>(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc, upper_only);
+	else if(t128 >= 192 && cfg == 5)
+		launch_gemm<128, 128, 64, 32, 0, 1, 2>(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc, upper_only);
+	else if(t128 >= 192 && cfg == 6 && k % 32 == 0)
+		launch_gemm<128, 128, 64, 32, 0, 1, 2, 32>(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc, upper_only);
+	else if(t128 >= 192 && cfg == 7 && k % 32 == 0)
+		launch_gemm<128, 128, 64, 32, 0, 2, 2, 32>(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc, upper_only);
+	else if(t128 >= 192 && cfg == 9)
+		launch_gemm<128, 128, 32, 32, 0, 1, 1>(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc, upper_only);
+	else if(t128 >= 192 && cfg == 10)
+		launch_gemm<128, 64, 32, 32, 0, 1, 1>(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc, upper_only);
+	else if(t128 >= 192 && cfg == 11)
+		launch_gemm<256, 128, 64, 32, 0, 1, 1>(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc, upper_only);
+	else if(t128 >= 192 && cfg == 8 && k % 64 == 0)
+		launch_gemm<128, 128, 64, 32, 0, 1, 2, 64>(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc, upper_only);
 	else if(t128 >= 192 && cfg == 2)
 		launch_gemm<128, 128, 32, 64, 0>(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc, upper_only);
 	else if(t128 >= 192 && cfg == 3)
@@ -642,46 +685,66 @@ void dense_factor_steps(spp_ctx *ctx, double *d_A, int64_t ld, int64_t n, int64_
 			launch_gemm_staged<128, 16, 32, 16, 1>(st, NB, ncols - c1, NB, tinv, NB, d_A + k0 + c1 * ld, ld,
 				d_A + k0 + c1 * ld, ld, false);
 	};
+	// Steps are processed in PAIRS: the bulk update applies two row panels at once (K = 256), which
+	// halves the read-modify-write traffic of the trailing matrix per flop (the K = 128 update sits on
+	// the HBM ridge: 8 flop/B). Within a pair the chain stream does
+	//   tile row k+1 <- panel k | potrf(k+1), panel k+1 | tile row k+2 <- panels k, k+1
+	// and the bulk stream updates everything below tile row k+2 with both panels.
+	auto tile_row = [&](int64_t r0, int64_t kp0, int npan) { // rows [r0, r0+128) x cols [r0, ncols) -= P^T P, panels at kp0
+		const int64_t m = std::min<int64_t>(NB, rows - r0);
+		if(m <= 0 || r0 >= ncols)
+			return;
+		for(int q = 0; q < npan; ++ q) {
+			const double *P = d_A + (kp0 + q * NB) + r0 * ld;
+			launch_gemm_staged<64, 64, 32, 32, 0>(s, m, ncols - r0, NB, P, ld, P, ld, d_A + r0 + r0 * ld, ld, true);
+		}
+	};
 	potrf_and_panel(s, 0);
 	bool bulk_pending = false;
-	for(int64_t k = 0; k < nsteps; ++ k) {
-		const int64_t k0 = k * NB, c1 = k0 + NB;
-		if(c1 >= ncols)
+	// pairing pays once the bulk update is shorter than the serial chain (it then hides anyway and the
+	// pair saves one cross-stream hand-off); while the trailing matrix is large the single-step schedule
+	// overlaps better. SPP_PAIR_BELOW = trailing rows below which steps are paired.
+	static int64_t pair_below = -1;
+	if(pair_below < 0) {
+		const char *e = getenv("SPP_PAIR_BELOW");
+		pair_below = e ? atol(e) : 0; // measured on Venice-871: pairing raises the update kernel's TFLOP/s but never the wall time
+	}
+	for(int64_t k = 0; k < nsteps;) {
+		const int64_t k0 = k * NB, c1 = k0 + NB, c2 = c1 + NB, c3 = c2 + NB;
+		const int npan = (rows - c1 < pair_below && k + 1 < nsteps) ? 2 : 1;
+		if(c1 >= ncols || rows - c1 <= 0)
 			break;
-		const int64_t mrest = ncols - c1;      // columns right of the block (incl. rhs)
-		const int64_t mrows = rows - c1;       // rows below the block that receive updates
-		if(mrows <= 0)
-			break;
-		const double *P = d_A + k0 + c1 * ld;  // row panel k: 128 x mrest
-		// the bulk update of step k-1 touched everything below/right of tile row k: it must be
-		// complete before tile row k+1 is updated again
+		// the bulk update of the previous pair touched every row >= c1
 		if(bulk_pending) {
 			SPP_HIP_CHECK(hipStreamWaitEvent(s, evB, 0));
 			bulk_pending = false;
 		}
-		if(mrows > NB)
-			SPP_HIP_CHECK(hipEventRecord(evA, s)); // row panel k is complete at this point of the chain
-		// (1) tile row k+1: rows [c1, c1+128) x cols [c1, ncols)   -- chain stream
-		const int64_t r1 = mrows < NB ? mrows : NB;
-		launch_gemm_staged<64, 64, 32, 32, 0>(s, r1, mrest, NB, P, ld, P, ld, d_A + c1 + c1 * ld, ld, true);
-		// (2) the rest: rows [c1+128, rows) x cols [c1+128, ncols)  -- bulk stream, needs panel k only
-		if(mrows > NB) {
-			const int64_t c2 = c1 + NB;
+		tile_row(c1, k0, 1);
+		if(npan == 2) {
+			potrf_and_panel(s, k + 1);
+			tile_row(c2, k0, 2);
+		}
+		// bulk: rows [cb, rows) x cols [cb, ncols) -= P^T P with P = rows [k0, k0 + 128 npan)
+		const int64_t cb = (npan == 2) ? c3 : c2;
+		if(rows - cb > 0 && cb < ncols) {
+			SPP_HIP_CHECK(hipEventRecord(evA, s)); // both panels (and the tile rows) are complete here
 			SPP_HIP_CHECK(hipStreamWaitEvent(s2, evA, 0));
+			const double *P = d_A + k0 + cb * ld;
 			hipStream_t keep = ctx->stream;
 			ctx->stream = s2; // dom events + gemm launch on the bulk stream
 			dom_begin(ctx);
-			dense_gemm_tn_sub(ctx, mrows - NB, mrest - NB, NB, P + NB * ld, ld, P + NB * ld, ld,
-				d_A + c2 + c2 * ld, ld, true);
-			const double mr = (double)(mrows - NB);
-			dom_end(ctx, 2.0 * NB * (0.5 * mr * mr + mr));
+			dense_gemm_tn_sub(ctx, rows - cb, ncols - cb, NB * npan, P, ld, P, ld, d_A + cb + cb * ld, ld, true);
+			const double mr = (double)(rows - cb);
+			// useful flops: upper triangle of the M x M part + the (N - M) extra columns (rhs)
+			dom_end(ctx, 2.0 * NB * npan * (0.5 * mr * (mr + 1.0) + mr * (double)(ncols - rows)));
 			ctx->stream = keep;
 			SPP_HIP_CHECK(hipEventRecord(evB, s2));
 			bulk_pending = true;
 		}
-		// (3) next diagonal block + row panel                        -- chain stream, overlaps (2)
-		if(k + 1 < nsteps)
-			potrf_and_panel(s, k + 1);
+		// next pair's first diagonal block + row panel overlaps the bulk update
+		if(k + npan < nsteps)
+			potrf_and_panel(s, k + npan);
+		k += npan;
 	}
 	if(bulk_pending)
 		SPP_HIP_CHECK(hipStreamWaitEvent(s, evB, 0));
