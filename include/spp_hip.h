@@ -118,6 +118,12 @@ int spp_factor_solve_device(spp_ctx *ctx, const double *d_vals, double *d_rhs_in
 int spp_schur_buffer_size(const spp_ctx *ctx, int64_t *n_doubles);
 int spp_schur_form(spp_ctx *ctx, const double *d_vals, const double *d_rhs, double *d_S_rhs);
 int spp_schur_finish(spp_ctx *ctx, const double *d_vals, double *d_S_rhs, double *d_rhs_inout);
+/* Only the upper block-trapezoid of S carries data: pack it (128-column panels, rows 0 .. end of the
+ * panel's diagonal block; 128^2 nblk (nblk + 1) / 2 doubles, about half of the square buffer) before
+ * the all-reduce and unpack afterwards -- halves the bytes that cross xGMI. */
+int spp_schur_packed_size(const spp_ctx *ctx, int64_t *n_doubles);
+int spp_schur_pack(spp_ctx *ctx, const double *d_S_rhs, double *d_packed);
+int spp_schur_unpack(spp_ctx *ctx, const double *d_packed, double *d_S_rhs);
 
 /* ---- Lambda / eta assembly ------------------------------------------------------------------------
  * replaces: CLambdaOps2::AddEntriesInSparseSystem + Alloc_HessianBlocks_v2 (symbolic;

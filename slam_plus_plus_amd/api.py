@@ -29,6 +29,7 @@ EXPORTS = [
     "spp_create", "spp_destroy", "spp_free_memory", "spp_last_error", "spp_set_stream", "spp_synchronize",
     "spp_analyze", "spp_set_shard", "spp_get_info", "spp_get_ordering", "spp_factor_solve",
     "spp_factor_solve_device", "spp_schur_buffer_size", "spp_schur_form", "spp_schur_finish",
+    "spp_schur_packed_size", "spp_schur_pack", "spp_schur_unpack",
     "spp_assemble_analyze", "spp_assemble_get_structure", "spp_assemble_device", "spp_device_malloc",
     "spp_device_free", "spp_memcpy_h2d", "spp_memcpy_d2h", "spp_memcpy_d2d", "spp_get_phase_ms", "spp_get_dominant_kernel",
     "spp_microbench_copy", "spp_microbench_mfma_f64", "spp_dense_potrf_upper", "spp_dense_posv",
@@ -70,6 +71,9 @@ def load_library():
         "spp_schur_buffer_size": (cint, [vp, _c_i64p]),
         "spp_schur_form": (cint, [vp, vp, vp, vp]),
         "spp_schur_finish": (cint, [vp, vp, vp, vp]),
+        "spp_schur_packed_size": (cint, [vp, _c_i64p]),
+        "spp_schur_pack": (cint, [vp, vp, vp]),
+        "spp_schur_unpack": (cint, [vp, vp, vp]),
         "spp_assemble_analyze": (cint, [vp, i64, vp, i64, vp, vp, cint, cint, cint, i64]),
         "spp_assemble_get_structure": (cint, [vp, vp, vp, vp]),
         "spp_assemble_device": (cint, [vp, vp, vp, vp, vp, dbl, vp, vp]),
@@ -207,6 +211,17 @@ class Context:
         out = ctypes.c_int64()
         self._check(self.lib.spp_schur_buffer_size(self.h, ctypes.byref(out)))
         return out.value
+
+    def schur_packed_size(self):
+        out = ctypes.c_int64()
+        self._check(self.lib.spp_schur_packed_size(self.h, ctypes.byref(out)))
+        return out.value
+
+    def schur_pack(self, d_S, d_packed):
+        return self._check(self.lib.spp_schur_pack(self.h, d_S, d_packed))
+
+    def schur_unpack(self, d_packed, d_S):
+        return self._check(self.lib.spp_schur_unpack(self.h, d_packed, d_S))
 
     def schur_form(self, d_vals, d_rhs, d_S):
         return self._check(self.lib.spp_schur_form(self.h, d_vals, d_rhs, d_S))

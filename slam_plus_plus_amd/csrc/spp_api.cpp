@@ -316,6 +316,41 @@ int spp_schur_form(spp_ctx *ctx, const double *d_vals, const double *d_rhs, doub
 	SPP_CATCH(ctx)
 }
 
+int spp_schur_packed_size(const spp_ctx *ctx, int64_t *n_doubles)
+{
+	if(!ctx || !n_doubles)
+		return SPP_E_BADARG;
+	if(ctx->mode != SPP_MODE_SCHUR)
+		return SPP_E_STATE;
+	const int64_t nblk = ctx->schur.ld / DENSE_NB;
+	*n_doubles = (int64_t)DENSE_NB * DENSE_NB * (nblk * (nblk + 1) / 2);
+	return SPP_OK;
+}
+
+int spp_schur_pack(spp_ctx *ctx, const double *d_S_rhs, double *d_packed)
+{
+	if(!ctx || !d_S_rhs || !d_packed)
+		return SPP_E_BADARG;
+	SPP_TRY(ctx)
+	SPP_REQUIRE(ctx->mode == SPP_MODE_SCHUR, SPP_E_STATE, "spp_schur_pack: analyze in Schur mode first");
+	SPP_HIP_CHECK(hipSetDevice(ctx->device));
+	schur_pack(ctx, const_cast<double*>(d_S_rhs), d_packed, true);
+	return SPP_OK;
+	SPP_CATCH(ctx)
+}
+
+int spp_schur_unpack(spp_ctx *ctx, const double *d_packed, double *d_S_rhs)
+{
+	if(!ctx || !d_S_rhs || !d_packed)
+		return SPP_E_BADARG;
+	SPP_TRY(ctx)
+	SPP_REQUIRE(ctx->mode == SPP_MODE_SCHUR, SPP_E_STATE, "spp_schur_unpack: analyze in Schur mode first");
+	SPP_HIP_CHECK(hipSetDevice(ctx->device));
+	schur_pack(ctx, d_S_rhs, const_cast<double*>(d_packed), false);
+	return SPP_OK;
+	SPP_CATCH(ctx)
+}
+
 int spp_schur_finish(spp_ctx *ctx, const double *d_vals, double *d_S_rhs, double *d_rhs_inout)
 {
 	if(!ctx || !d_vals || !d_rhs_inout || !d_S_rhs)

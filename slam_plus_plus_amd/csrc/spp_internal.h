@@ -183,6 +183,7 @@ int64_t sparse_info(const spp_ctx *ctx, int what);
 // ---- spp_schur.hip ----
 void schur_form(spp_ctx *ctx, const double *d_vals, const double *d_rhs, double *d_S_rhs);
 int schur_finish(spp_ctx *ctx, const double *d_vals, double *d_S_rhs, double *d_rhs);
+void schur_pack(spp_ctx *ctx, double *S, double *packed, bool pack);
 
 // ---- spp_dense.hip ----
 constexpr int DENSE_NB = 128;

@@ -377,6 +377,37 @@ static int schur_finish_t(spp_ctx *ctx, const double *d_vals, double *S, double 
 	return SPP_OK;
 }
 
+// packed upper trapezoid: panel k (columns 128 k ..) keeps rows [0, 128 (k + 1)), column-major inside
+// the panel; panel offset = 128 * 128 * k (k + 1) / 2 doubles
+template <bool PACK>
+__global__ __launch_bounds__(256)
+void schur_pack_kernel(double *__restrict__ S, int64_t ld, double *__restrict__ packed)
+{
+	const int64_t k = blockIdx.y;                 // panel
+	const int64_t rows = 128 * (k + 1);
+	const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; // element inside the panel (rows x 128)
+	if(e >= rows * 128)
+		return;
+	const int64_t r = e % rows, c = e / rows;
+	double *ps = S + r + (128 * k + c) * ld;
+	double *pp = packed + 128 * 128 * (k * (k + 1) / 2) + e;
+	if(PACK)
+		*pp = *ps;
+	else
+		*ps = *pp;
+}
+
+void schur_pack(spp_ctx *ctx, double *S, double *packed, bool pack)
+{
+	const int64_t ld = ctx->schur.ld, nblk = ld / 128;
+	dim3 grid((unsigned)((ld * 128 + 255) / 256), (unsigned)nblk);
+	if(pack)
+		hipLaunchKernelGGL((schur_pack_kernel<true>), grid, dim3(256), 0, ctx->stream, S, ld, packed);
+	else
+		hipLaunchKernelGGL((schur_pack_kernel<false>), grid, dim3(256), 0, ctx->stream, S, ld, packed);
+	SPP_HIP_CHECK(hipGetLastError());
+}
+
 void schur_form(spp_ctx *ctx, const double *d_vals, const double *d_rhs, double *d_S_rhs)
 {
 	if(ctx->schur.dp == 6)

@@ -31,11 +31,23 @@ def test_sharded_schur_equals_unsharded(name, world):
         ctxs.append(c)
         bufs.append((dv, dr, dS))
     assert sum(c.info("N_LANDMARKS") for c in ctxs) == int((lam.dim == 3).sum())
-    total = sum(b[2].download() for b in bufs)  # the all-reduce
+    # pack -> sum -> unpack: what bench.py sends through the RCCL all-reduce (upper trapezoid only)
+    packed = []
+    for c, (dv, dr, dS) in zip(ctxs, bufs):
+        dP = api.DeviceArray(c, c.schur_packed_size())
+        c.schur_pack(dS.ptr, dP.ptr)
+        c.synchronize()
+        packed.append(dP)
+    assert packed[0].n < 0.6 * bufs[0][2].n
+    psum = sum(p.download() for p in packed)  # the all-reduce
+    for c, (dv, dr, dS), dP in zip(ctxs, bufs, packed):
+        dP.upload(psum)
+        c.schur_unpack(dP.ptr, dS.ptr)
+        c.synchronize()
+    total = bufs[0][2].download()
     x = np.zeros_like(eta)
     dl = int(lam.dim.min())
     for r, (c, (dv, dr, dS)) in enumerate(zip(ctxs, bufs)):
-        dS.upload(total)
         assert c.schur_finish(dv.ptr, dS.ptr, dr.ptr) == 0
         c.synchronize()
         xr = dr.download()
