@@ -212,7 +212,8 @@ def main():
                            "launches_per_solve": int(dom_n), "avg_launch_ms": dom_ms / dom_n,
                            "flops_per_launch": dom_flops / dom_n,
                            "measured_mfma_f64_peak": ctx.microbench_mfma_f64(4000),
-                           "measured_copy_gbs": ctx.microbench_copy(1 << 30, 10)}
+                           "measured_copy_gbs": ctx.microbench_copy(1 << 30, 10),
+                           "measured_ctile_rw_gbs": ctx.microbench_ctile(8192, 5)}
         # the HBM-bound part of the solve, for reference: algorithmic bytes / time of the Schur phases
         sch_ms = phase["schur_inv"] + phase["schur_gemm"] + phase["schur_rhs"] + phase["backsubst"]
         if sch_ms > 0:

@@ -174,6 +174,9 @@ int spp_get_dominant_kernel(spp_ctx *ctx, double *ms_total, int64_t *n_launches,
 /* ---- micro-benchmarks used by bench.py to report measured peaks beside the spec peaks ------------ */
 int spp_microbench_copy(spp_ctx *ctx, size_t bytes, int iters, double *gb_per_s);
 int spp_microbench_mfma_f64(spp_ctx *ctx, int iters, double *tflops);
+/* read-negate-write of an n x n fp64 matrix (n % 128 == 0) in the trailing-update kernel's C-tile lane
+   pattern; a known byte count (2 * 8 * n * n per launch) to calibrate the PMC traffic counters with */
+int spp_microbench_ctile(spp_ctx *ctx, int n, int iters, double *gb_per_s);
 
 /* direct access to the dense kernels for unit tests (device pointers; A is n x n col-major, ld) */
 int spp_dense_potrf_upper(spp_ctx *ctx, double *d_A, int64_t n, int64_t ld);

@@ -32,7 +32,7 @@ EXPORTS = [
     "spp_schur_packed_size", "spp_schur_pack", "spp_schur_unpack",
     "spp_assemble_analyze", "spp_assemble_get_structure", "spp_assemble_device", "spp_device_malloc",
     "spp_device_free", "spp_memcpy_h2d", "spp_memcpy_d2h", "spp_memcpy_d2d", "spp_get_phase_ms", "spp_get_dominant_kernel",
-    "spp_microbench_copy", "spp_microbench_mfma_f64", "spp_dense_potrf_upper", "spp_dense_posv",
+    "spp_microbench_copy", "spp_microbench_mfma_f64", "spp_microbench_ctile", "spp_dense_potrf_upper", "spp_dense_posv",
     "spp_dense_gemm_tn_sub", "spp_version",
 ]
 
@@ -86,6 +86,7 @@ def load_library():
         "spp_get_dominant_kernel": (cint, [vp, _c_f64p, _c_i64p, _c_f64p]),
         "spp_microbench_copy": (cint, [vp, ctypes.c_size_t, cint, _c_f64p]),
         "spp_microbench_mfma_f64": (cint, [vp, cint, _c_f64p]),
+        "spp_microbench_ctile": (cint, [vp, cint, cint, _c_f64p]),
         "spp_dense_potrf_upper": (cint, [vp, vp, i64, i64]),
         "spp_dense_posv": (cint, [vp, vp, i64, i64, vp]),
         "spp_dense_gemm_tn_sub": (cint, [vp, i64, i64, i64, vp, i64, vp, i64, vp, i64]),
@@ -261,6 +262,11 @@ class Context:
     def microbench_copy(self, nbytes=1 << 30, iters=10):
         out = ctypes.c_double()
         self._check(self.lib.spp_microbench_copy(self.h, nbytes, iters, ctypes.byref(out)))
+        return out.value
+
+    def microbench_ctile(self, n=8192, iters=10):
+        out = ctypes.c_double()
+        self._check(self.lib.spp_microbench_ctile(self.h, n, iters, ctypes.byref(out)))
         return out.value
 
     def microbench_mfma_f64(self, iters=4000):

@@ -542,6 +542,17 @@ int spp_microbench_copy(spp_ctx *ctx, size_t bytes, int iters, double *gb_per_s)
 	SPP_CATCH(ctx)
 }
 
+int spp_microbench_ctile(spp_ctx *ctx, int n, int iters, double *gb_per_s)
+{
+	if(!ctx || !gb_per_s)
+		return SPP_E_BADARG;
+	SPP_TRY(ctx)
+	SPP_HIP_CHECK(hipSetDevice(ctx->device));
+	*gb_per_s = microbench_ctile(ctx, n, iters);
+	return SPP_OK;
+	SPP_CATCH(ctx)
+}
+
 int spp_microbench_mfma_f64(spp_ctx *ctx, int iters, double *tflops)
 {
 	if(!ctx || !tflops)

@@ -30,6 +30,7 @@
 #include "spp_internal.h"
 #include "spp_tiles.h"
 #include <stdlib.h>
+#include <string.h>
 #include <algorithm>
 
 namespace spp {
@@ -379,6 +380,13 @@ void dense_gemm_tn_sub(spp_ctx *ctx, int64_t m, int64_t n, int64_t k, const doub
 // 2 workgroup barriers per panel. Dinv / G_JJ scratch tiles are double buffered (panel parity).
 // info[0] = first failing global pivot index + 1 (non-positive pivot, Eigen's LLT test).
 // --------------------------------------------------------------------------------------------------
+#ifdef SPP_POTRF_TRACE
+__device__ long long spp_potrf_trace[64]; // cycle stamps of thread 0 / thread 64 (tools/potrf_trace.hip)
+#define SPP_STAMP(slot, who) do { if(tid == (who)) spp_potrf_trace[slot] = (long long)__builtin_readcyclecounter(); } while(0)
+#else
+#define SPP_STAMP(slot, who) do { } while(0)
+#endif
+
 constexpr int NB = DENSE_NB;
 constexpr int TS = NB + 1;   // LDS column stride of the block image: element (r, c) at r + c * TS
 constexpr int POTRF_THREADS = 1024;
@@ -389,13 +397,14 @@ void potrf_diag_kernel(double *__restrict__ Ablk, int64_t ld, int n_valid, int h
 	double *__restrict__ tinv, int *__restrict__ info, int64_t k0)
 {
 	extern __shared__ double sm[];
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	SPP_STAMP(0, 0);
 	double *T = sm;                  // NB x NB image, stride TS
 	double *DvB = T + NB * TS;       // 2 x Dinv[k][i] at Dv[k + i * PT] (upper triangular, zeros below)
 	double *GdB = DvB + 2 * 16 * PT; // 2 x G_JJ[r][c] = Dinv[c][r] at Gd[r + c * PT] (lower triangular incl. diagonal)
 	double *dinv = GdB + 2 * 16 * PT; // 1 / R[j][j]
 	double *yv = dinv + NB;          // carried right-hand side
 	int *fail = (int*)(yv + NB);
-	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int l15 = lane & 15, l4 = lane >> 4;
 	constexpr int NW = POTRF_THREADS / 64;
 	{
@@ -416,6 +425,7 @@ void potrf_diag_kernel(double *__restrict__ Ablk, int64_t ld, int n_valid, int h
 	if(tid == 0)
 		*fail = 0;
 	__syncthreads();
+	SPP_STAMP(1, 0);
 	const int rhs_col = (has_rhs && n_valid < NB) ? n_valid : -1;
 	if(tid < NB) {
 		yv[tid] = (rhs_col >= 0 && tid < n_valid) ? T[tid + rhs_col * TS] : 0.0;
@@ -428,10 +438,12 @@ void potrf_diag_kernel(double *__restrict__ Ablk, int64_t ld, int n_valid, int h
 	if(wave == 0)
 		diag_tile_factor<TS>(T, DvB, GdB, dinv, 0, lane, fail, info, k0);
 	__syncthreads();
+	SPP_STAMP(2, 0);
 
 	for(int J = 0; J < NB / 16; ++ J) {
 		if(*fail)
 			return;
+		SPP_STAMP(3 + 6 * J, 0);
 		const int j0 = J * 16;
 		const double *Dv = DvB + (J & 1) * 16 * PT, *Gd = GdB + (J & 1) * 16 * PT;
 		// ---- B: row panel. tiles t < J: G part (columns 16 t ..), tiles t >= J: R part (columns 16 (t + 1) ..)
@@ -452,7 +464,10 @@ void potrf_diag_kernel(double *__restrict__ Ablk, int64_t ld, int n_valid, int h
 			__builtin_amdgcn_wave_barrier();
 			yv[j0 + lane] = s;
 		}
+		SPP_STAMP(4 + 6 * J, 0);
 		__syncthreads();
+		SPP_STAMP(5 + 6 * J, 0);
+		SPP_STAMP(6 + 6 * J, 64);
 		// ---- C (+ A of the next panel on wave 0): trailing update with the panel rows P = T[j0 .. j0 + 16, :]
 		{
 			const int nI = NB / 16 - 1 - J;         // row tiles I = J + 1 .. 7
@@ -534,8 +549,11 @@ void potrf_diag_kernel(double *__restrict__ Ablk, int64_t ld, int n_valid, int h
 				}
 			}
 		}
+		SPP_STAMP(7 + 6 * J, 0);
+		SPP_STAMP(8 + 6 * J, 64);
 		__syncthreads();
 	}
+	SPP_STAMP(51, 0);
 	if(*fail)
 		return;
 	// ---- write back R (upper triangle), the carried rhs, and the dense upper-triangular inverse
@@ -552,6 +570,7 @@ void potrf_diag_kernel(double *__restrict__ Ablk, int64_t ld, int n_valid, int h
 	}
 	if(rhs_col >= 0 && tid < n_valid)
 		Ablk[tid + (int64_t)rhs_col * ld] = yv[tid];
+	SPP_STAMP(52, 0);
 }
 
 // backward substitution step for block column k (rows/cols k0 .. k0 + NB):
@@ -640,9 +659,13 @@ static void ensure_dense_work(spp_ctx *ctx, int64_t nblk)
 	ctx->dense.tinv_all.reserve((size_t)nblk * NB * NB);
 	ctx->dense.xtmp.reserve((size_t)(nblk + 1) * NB);
 	if(!ctx->dense.aux) {
-		int prio_lo = 0, prio_hi = 0; // the serial chain of the factorization preempts the bulk update
+		// the bulk update runs at the LOWEST priority: workgroups of the serial chain (on ctx->stream)
+		// are dispatched first whenever a CU frees up under a running trailing update
+		int prio_lo = 0, prio_hi = 0;
 		SPP_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-		SPP_HIP_CHECK(hipStreamCreateWithPriority(&ctx->dense.aux, hipStreamNonBlocking, prio_hi));
+		const char *e = getenv("SPP_AUX_PRIO");
+		SPP_HIP_CHECK(hipStreamCreateWithPriority(&ctx->dense.aux, hipStreamNonBlocking,
+			(e && !strcmp(e, "hi")) ? prio_hi : prio_lo));
 		SPP_HIP_CHECK(hipEventCreateWithFlags(&ctx->dense.ev[0], hipEventDisableTiming));
 		SPP_HIP_CHECK(hipEventCreateWithFlags(&ctx->dense.ev[1], hipEventDisableTiming));
 	}
@@ -709,25 +732,41 @@ void dense_factor_steps(spp_ctx *ctx, double *d_A, int64_t ld, int64_t n, int64_
 		const char *e = getenv("SPP_PAIR_BELOW");
 		pair_below = e ? atol(e) : 0; // measured on Venice-871: pairing raises the update kernel's TFLOP/s but never the wall time
 	}
+	static int eva_early = -1;
+	if(eva_early < 0) {
+		const char *e = getenv("SPP_EVA_EARLY");
+		eva_early = e ? atoi(e) : 1;
+	}
 	for(int64_t k = 0; k < nsteps;) {
 		const int64_t k0 = k * NB, c1 = k0 + NB, c2 = c1 + NB, c3 = c2 + NB;
 		const int npan = (rows - c1 < pair_below && k + 1 < nsteps) ? 2 : 1;
 		if(c1 >= ncols || rows - c1 <= 0)
 			break;
-		// the bulk update of the previous pair touched every row >= c1
+		// A single-panel bulk update needs only row panel k (complete at this point of the chain stream)
+		// and writes rows >= c2, disjoint from the tile row the chain touches next: hand it to the bulk
+		// stream BEFORE the tile row, so that consecutive bulk updates run back to back.
+		const bool early = (npan == 1) && eva_early;
+		if(early)
+			SPP_HIP_CHECK(hipEventRecord(evA, s));
+		// the bulk update of the previous pair touched every row >= c1 (evB still names that update:
+		// this wait is issued before the next record)
 		if(bulk_pending) {
 			SPP_HIP_CHECK(hipStreamWaitEvent(s, evB, 0));
 			bulk_pending = false;
 		}
-		tile_row(c1, k0, 1);
-		if(npan == 2) {
-			potrf_and_panel(s, k + 1);
-			tile_row(c2, k0, 2);
+		const int64_t cb = (npan == 2) ? c3 : c2;
+		const bool have_bulk = rows - cb > 0 && cb < ncols;
+		if(!early || !have_bulk) {
+			tile_row(c1, k0, 1);
+			if(npan == 2) {
+				potrf_and_panel(s, k + 1);
+				tile_row(c2, k0, 2);
+			}
 		}
 		// bulk: rows [cb, rows) x cols [cb, ncols) -= P^T P with P = rows [k0, k0 + 128 npan)
-		const int64_t cb = (npan == 2) ? c3 : c2;
-		if(rows - cb > 0 && cb < ncols) {
-			SPP_HIP_CHECK(hipEventRecord(evA, s)); // both panels (and the tile rows) are complete here
+		if(have_bulk) {
+			if(!early)
+				SPP_HIP_CHECK(hipEventRecord(evA, s)); // both panels (and the tile rows) are complete here
 			SPP_HIP_CHECK(hipStreamWaitEvent(s2, evA, 0));
 			const double *P = d_A + k0 + cb * ld;
 			hipStream_t keep = ctx->stream;
@@ -740,6 +779,8 @@ void dense_factor_steps(spp_ctx *ctx, double *d_A, int64_t ld, int64_t n, int64_
 			ctx->stream = keep;
 			SPP_HIP_CHECK(hipEventRecord(evB, s2));
 			bulk_pending = true;
+			if(early)
+				tile_row(c1, k0, 1);
 		}
 		// next pair's first diagonal block + row panel overlaps the bulk update
 		if(k + npan < nsteps)
@@ -827,6 +868,54 @@ double microbench_copy(spp_ctx *ctx, size_t bytes, int iters)
 	(void)hipEventDestroy(e0);
 	(void)hipEventDestroy(e1);
 	return 2.0 * n * sizeof(double2) * iters / (ms * 1e-3) * 1e-9;
+}
+
+// The trailing-update kernel's C-tile access pattern in isolation (8 B per lane, four 128-byte column
+// segments per wave instruction, 128x128 tile per 1024-thread workgroup): reads C and writes -C back.
+// A known byte count in exactly this pattern calibrates FETCH_SIZE / WRITE_SIZE for that kernel.
+__global__ __launch_bounds__(1024)
+void ctile_rw_kernel(double *C, int64_t ldc)
+{
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int l15 = lane & 15, l4 = lane >> 4;
+	const int64_t m0 = (int64_t)blockIdx.x * 128 + (wave % 4) * 32, n0 = (int64_t)blockIdx.y * 128 + (wave / 4) * 32;
+	double v[2][2][4];
+#pragma unroll
+	for(int b = 0; b < 2; ++ b)
+#pragma unroll
+		for(int a = 0; a < 2; ++ a)
+#pragma unroll
+			for(int r = 0; r < 4; ++ r)
+				v[b][a][r] = C[m0 + a * 16 + l15 + (n0 + b * 16 + l4 + 4 * r) * ldc];
+#pragma unroll
+	for(int b = 0; b < 2; ++ b)
+#pragma unroll
+		for(int a = 0; a < 2; ++ a)
+#pragma unroll
+			for(int r = 0; r < 4; ++ r)
+				C[m0 + a * 16 + l15 + (n0 + b * 16 + l4 + 4 * r) * ldc] = -v[b][a][r];
+}
+
+double microbench_ctile(spp_ctx *ctx, int n, int iters)
+{
+	SPP_REQUIRE(n > 0 && n % 128 == 0, SPP_E_BADARG, "ctile microbenchmark: n must be a multiple of 128");
+	DevBuf<double> c;
+	c.reserve((size_t)n * n);
+	SPP_HIP_CHECK(hipMemsetAsync(c.p, 0, (size_t)n * n * sizeof(double), ctx->stream));
+	hipEvent_t e0, e1;
+	SPP_HIP_CHECK(hipEventCreate(&e0));
+	SPP_HIP_CHECK(hipEventCreate(&e1));
+	hipLaunchKernelGGL(ctile_rw_kernel, dim3(n / 128, n / 128), dim3(1024), 0, ctx->stream, c.p, (int64_t)n);
+	SPP_HIP_CHECK(hipEventRecord(e0, ctx->stream));
+	for(int i = 0; i < iters; ++ i)
+		hipLaunchKernelGGL(ctile_rw_kernel, dim3(n / 128, n / 128), dim3(1024), 0, ctx->stream, c.p, (int64_t)n);
+	SPP_HIP_CHECK(hipEventRecord(e1, ctx->stream));
+	SPP_HIP_CHECK(hipEventSynchronize(e1));
+	float ms = 0;
+	SPP_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+	(void)hipEventDestroy(e0);
+	(void)hipEventDestroy(e1);
+	return 2.0 * n * n * sizeof(double) * iters / (ms * 1e-3) * 1e-9;
 }
 
 __global__ __launch_bounds__(256)

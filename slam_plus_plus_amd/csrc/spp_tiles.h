@@ -4,6 +4,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef SPP_TILE_STAMP
+#define SPP_TILE_STAMP(k, v) do { } while(0)
+#endif
+#ifndef SPP_PIVOT_STAMP
+#define SPP_PIVOT_STAMP(j, v) do { } while(0)
+#endif
+
 namespace spp {
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
@@ -16,6 +23,21 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane)
 	u.d = v;
 	u.i[0] = __builtin_amdgcn_readlane(u.i[0], src_lane);
 	u.i[1] = __builtin_amdgcn_readlane(u.i[1], src_lane);
+	return u.d;
+}
+
+// bit j of a per-lane mask as 0 / ~0 (v_bfe_i32), and a double AND-ed with such a word: VGPR-only masking
+__device__ __forceinline__ int sbit(unsigned mask, int j)
+{
+	return ((int)(mask << (31 - j))) >> 31;
+}
+
+__device__ __forceinline__ double and_f64(double v, int word)
+{
+	union { double d; int i[2]; } u;
+	u.d = v;
+	u.i[0] &= word;
+	u.i[1] &= word;
 	return u.d;
 }
 
@@ -57,73 +79,112 @@ __device__ __forceinline__ void tile_atb2_rt(const int TS, const double *a0, con
 }
 
 // step A: factor + invert the 16 x 16 diagonal tile at (j0, j0) in registers (one wave).
-// Lane (c = l & 15, g = l >> 4) owns rows 4g..4g+3 of column c. The strictly lower half accumulates
-// G = (R_JJ^-1)^T:  pivot j, row i > j, f = W[j][i] / p_j:
-//     c < j : W[i][c] -= f W[j][c]   (G update)      c == j: W[i][j] = -f   (new G entry)
-//     c >= i: W[i][c] -= f W[j][c]   (trailing update)
+// The symmetric tile W lives in the MFMA accumulator layout: lane (c = l & 15, q = l >> 4) holds
+// W[q + 4 r][c] in acc[r]. The rank-1 update of pivot j,
+//     W[i][c] -= (W[j][i] / p_j) W[j][c]      rows i > j, columns c != j,
+// is ONE v_mfma_f64_16x16x4: row j sits in the lanes q == (j & 3) (register j >> 2), which feed it
+// unmoved as both operands (A[i][k] = -W[j][i] / p_j for i > j, B[k][c] = W[j][c] for c != j, zero in
+// the other three k slots) -- the matrix core does the broadcast, no lane shuffles, no LDS.
+// The next pivot W[j+1][j+1] - (W[j][j+1] / p_j) W[j][j+1] is formed beside the MFMA from two
+// v_readlane'd scalars, so its reciprocal (v_rcp_f64 + one Newton step) overlaps the MFMA; the serial
+// chain per pivot is one MFMA plus the operand scaling.
+// Rows i > c of column c first carry the mirrored (lower) half of the trailing matrix; column c is left
+// out of its own pivot, and from then on those rows evolve, through the very same update, into column
+// c of G = (R_JJ^-1)^T up to the factor -1 / p_c, applied once at the end (the updates are linear in
+// the column, so the scaling commutes with them).
 // Writes R (upper) and G (strictly lower) into T, Dinv / G_JJ into the scratch tiles, 1/R_jj into dinv.
 __device__ __forceinline__ void diag_tile_factor_rt(const int TS, double *T, double *Dv, double *Gd, double *dinv, int j0,
 	int lane, int *fail, int *info, int64_t k0)
 {
-	const int l15 = lane & 15, l4 = lane >> 4;
-	double x[4];
+	const int c = lane & 15, q = lane >> 4;
+	SPP_TILE_STAMP(0, 0.0);
+	v4f64 acc;
 #pragma unroll
-	for(int t = 0; t < 4; ++ t) {
-		const int i = 4 * l4 + t;
-		x[t] = (i <= l15) ? T[(j0 + i) + (j0 + l15) * TS] : 0.0;
+	for(int r = 0; r < 4; ++ r) {
+		const int i = q + 4 * r;
+		acc[r] = T[(i <= c) ? (j0 + i) + (j0 + c) * TS : (j0 + c) + (j0 + i) * TS];
 	}
-	bool bad = false;
+	// Measured on gfx950 (tools/lat_bench.hip, lat_bench2.hip): a dependent v_mfma_f64_16x16x4 chain with
+	// both operands rebuilt from the accumulator runs at ~105 cycles per MFMA; a VALU instruction that
+	// writes an SGPR while the wave's MFMA is in flight (v_readlane, v_cmp) adds 70-100 cycles, a
+	// compare + select mask pair ~15. Hence: the two v_readlane'd scalars of the next pivot are taken
+	// BEFORE the MFMA is issued, the lane masks are per-lane bit sets built before the loop and applied
+	// as AND words, and the pivot test runs once after the loop on the diagonal itself.
+	// (bit-AND with 0 / ~0: exact zeros even when a failed pivot has produced NaNs; after an exactly zero
+	// pivot the NaNs still spread through B, the factorization is then reported as failed, at worst
+	// with an earlier pivot index than the true one).
+	//   A mask, bit j: lane feeds row i = c > j in k slot q == (j & 3);  B mask, bit j: not (slot q, column j)
+	const unsigned amask = (0x1111u << q) & ((1u << c) - 1u);
+	const unsigned bmask = ~(((c & 3) == q) ? (1u << c) : 0u);
+	double p = readlane_f64(acc[0], 0);
+	SPP_TILE_STAMP(1, p);
+	double r0 = __builtin_amdgcn_rcp(p);
+	double pinv = r0 * (2.0 - p * r0); // v_rcp_f64 + one Newton step
+	int aw = sbit(amask, 0), bw = sbit(bmask, 0);
 #pragma unroll
-	for(int j = 0; j < 16; ++ j) {
-		const int src = j | ((j >> 2) << 4); // lane holding W[j][j] in register j & 3 (compile-time)
-		const double p = readlane_f64(x[j & 3], src);
-		if(!(p > 0)) {
-			if(!bad && lane == 0) {
+	for(int j = 0; j < 15; ++ j) {
+		const int qj = j & 3, rj = j >> 2;
+		// ---- between two MFMAs (the serial chain): as few instructions as possible
+		const double rowv = acc[rj];
+		const double diag = acc[(j + 1) >> 2];
+		const double aop = and_f64(-rowv * pinv, aw); // A[i][k]: -W[j][i] / p_j for rows i > j
+		const double bop = and_f64(rowv, bw);         // B[k][c]:  W[j][c], column j dropped
+		// scalars of the next pivot: W[j][j+1] and W[j+1][j+1] before this pivot's update
+		const double wj = readlane_f64(rowv, (j + 1) | (qj << 4));
+		const double wd = readlane_f64(diag, (j + 1) | (((j + 1) & 3) << 4));
+		__builtin_amdgcn_sched_barrier(0);
+		acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
+		__builtin_amdgcn_sched_barrier(0);
+		// ---- in the MFMA's shadow (VGPR results only): the next pivot, rounded exactly like the MFMA's
+		// own update of W[j+1][j+1], its reciprocal, and the next mask words
+		p = __builtin_fma(-wj * pinv, wj, wd);
+		r0 = __builtin_amdgcn_rcp(p);
+		pinv = r0 * (2.0 - p * r0);
+		aw = sbit(amask, j + 1);
+		bw = sbit(bmask, j + 1);
+		asm volatile("" : "+v"(pinv), "+v"(aw), "+v"(bw)); // keep these before the wait for the MFMA
+		__builtin_amdgcn_sched_barrier(0);
+		SPP_PIVOT_STAMP(j, p);
+	}
+	SPP_TILE_STAMP(2, acc[0] + acc[1] + acc[2] + acc[3] + p);
+	// the lanes with (c & 3) == q hold the diagonal p_c in acc[c >> 2]; 1 / sqrt(p_i) is exchanged via dinv
+	double pc = acc[0];
+#pragma unroll
+	for(int r = 1; r < 4; ++ r)
+		pc = ((c >> 2) == r) ? acc[r] : pc;
+	// Eigen's LLT test (non-positive or NaN pivot) on the diagonal lanes; the first failing column is
+	// exact because the pivots before it do not depend on it
+	{
+		const unsigned long long bl = __builtin_amdgcn_ballot_w64(((c & 3) == q) && !(pc > 0));
+		if(bl) {
+			const unsigned m16 = (unsigned)((bl & 0x1111u) | ((bl >> 16) & 0x2222u) | ((bl >> 32) & 0x4444u) | ((bl >> 48) & 0x8888u));
+			if(lane == 0) {
 				*fail = 1;
-				info[0] = (int)(k0 + j0 + j + 1);
+				info[0] = (int)(k0 + j0 + __builtin_ctz(m16) + 1);
 			}
-			bad = true;
-		}
-		double pinv = __builtin_amdgcn_rcp(p); // v_rcp_f64 + one Newton step
-		pinv = pinv * (2.0 - p * pinv);
-		const double rowj_c = __shfl(x[j & 3], l15 | ((j >> 2) << 4)); // W[j][c]
-#pragma unroll
-		for(int t = 0; t < 4; ++ t) {
-			const int i = 4 * l4 + t;
-			const double f = __shfl(x[j & 3], i | ((j >> 2) << 4)) * pinv; // W[j][i] / p
-			const bool below = i > j;
-			const double upd = x[t] - f * rowj_c;
-			x[t] = (below && l15 == j) ? -f : ((below && (l15 < j || l15 >= i)) ? upd : x[t]);
+			return;
 		}
 	}
-	if(bad)
-		return;
-	double pv[4];
+	const double sq = sqrt(pc); // R_cc (meaningful in the diagonal lanes)
+	if((c & 3) == q)
+		dinv[j0 + c] = 1.0 / sq;
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	const double pvc = dinv[j0 + c];
+	SPP_TILE_STAMP(3, pvc);
+	const double g = -pvc * pvc; // -1 / p_c: the deferred scale of column c of G
 #pragma unroll
-	for(int t = 0; t < 4; ++ t) {
-		const int i = 4 * l4 + t;
-		pv[t] = 1.0 / sqrt(__shfl(x[t], i | (l4 << 4))); // 1 / sqrt(W[i][i])
+	for(int r = 0; r < 4; ++ r) {
+		const int i = q + 4 * r;
+		const double pvi = dinv[j0 + i];
+		// i < c: R[i][c] = w / sqrt(p_i);  i > c: G[i][c] = (-w / p_c) / sqrt(p_i) = Dinv[c][i]
+		const double w = (i == c) ? pvc : acc[r] * pvi * ((i > c) ? g : 1.0);
+		T[(j0 + i) + (j0 + c) * TS] = (i == c) ? sq : w;
+		const double d = (i < c) ? 0.0 : w;
+		Dv[c + i * PT] = d;   // Dinv[c][i] (upper triangular, zero for c > i)
+		Gd[i + c * PT] = d;   // G[i][c]   (lower triangular incl. the diagonal)
 	}
-#pragma unroll
-	for(int t = 0; t < 4; ++ t) {
-		const int i = 4 * l4 + t, c = l15;
-		const double w = x[t], pi = pv[t];
-		if(i < c) {          // R[i][c] = w / sqrt(p_i)
-			T[(j0 + i) + (j0 + c) * TS] = w * pi;
-			Dv[c + i * PT] = 0.0;   // Dinv[c][i], c > i: below the diagonal
-			Gd[i + c * PT] = 0.0;   // G[i][c], c > i
-		} else if(i == c) {
-			T[(j0 + i) + (j0 + i) * TS] = 1.0 / pi;
-			Dv[i + i * PT] = pi;
-			Gd[i + i * PT] = pi;
-			dinv[j0 + i] = pi;
-		} else {             // G[i][c] = w / sqrt(p_i), c < i  (= Dinv[c][i])
-			const double g = w * pi;
-			T[(j0 + i) + (j0 + c) * TS] = g;
-			Dv[c + i * PT] = g;
-			Gd[i + c * PT] = g;
-		}
-	}
+	SPP_TILE_STAMP(4, 0.0);
 }
 
 

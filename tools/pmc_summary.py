@@ -42,8 +42,9 @@ def main():
             for r in rows:
                 fo.write('"%s",%d,%.3f,%d,%.3f,%.0f\n' % r)
     dom = [r for r in rows if sub in r[0]]
-    dom.sort(key=lambda r: -r[1])
+    dom.sort(key=lambda r: -r[1] * r[5])   # the variant that moves the most bytes in total
     k = dom[0]
+    cal = [r for r in rows if "ctile_rw_kernel" in r[0]]
     js = json.load(open(out_json)) if os.path.exists(out_json) else {}
     js[workload] = {
         "kernel": k[0], "bytes_per_launch": k[5], "fetch_size_kb_avg": k[2], "write_size_kb_avg": k[4],
@@ -51,6 +52,12 @@ def main():
         "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (with --kernel-trace only); "
                "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 FETCH_SIZE reports half of 16-B/lane streaming reads, "
                "MI355X_MICROARCH.md HBM section); tools/pmc_summary.py"}
+    if cal:
+        # known byte count in the kernel's own C-tile access pattern (8 B/lane): 8 * n * n each way, n = 8192
+        known = 8.0 * 8192 * 8192
+        js[workload]["calibration_ctile_8B_per_lane"] = {
+            "known_bytes_each_way": known, "FETCH_SIZE_KiB_avg": cal[0][2], "WRITE_SIZE_KiB_avg": cal[0][4],
+            "true_over_FETCH_SIZE": known / (cal[0][2] * 1024), "true_over_WRITE_SIZE": known / (cal[0][4] * 1024)}
     json.dump(js, open(out_json, "w"), indent=1)
     print(json.dumps(js[workload], indent=1))
 
