@@ -119,6 +119,7 @@ def main():
     nnzb = st.nnzb
 
     S = P = None
+    schur = mode in (api.MODE_SCHUR, api.MODE_SCHUR_SPARSE)
     if mode == api.MODE_SCHUR and world > 1:
         S = torch.empty(ctx.schur_buffer_size(), dtype=torch.float64, device="cuda")
         P = torch.empty(ctx.schur_packed_size(), dtype=torch.float64, device="cuda")  # upper trapezoid only
@@ -187,7 +188,8 @@ def main():
         "higher_is_better": True, "scaling": "weak" if (weak or world == 1) else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%s-shaped synthetic BA (%d cams, %d points, %d observations, LM-damped)" % (
             args.workload, prob.get("nc", 0), prob.get("npts", 0), prob.v0.size) if "nc" in prob else args.workload,
-            "nnzb": int(nnzb), "n": int(st.n), "mode": "schur+dense" if mode == api.MODE_SCHUR else "sparse multifrontal",
+            "nnzb": int(nnzb), "n": int(st.n), "mode": {api.MODE_SCHUR: "schur+dense", api.MODE_SCHUR_SPARSE: "schur+sparse reduced system",
+                                                            api.MODE_SPARSE: "sparse multifrontal"}[mode],
             "n_reduced": int(ctx.info("N_REDUCED")), "schur_pairs": int(ctx.info("SCHUR_PAIRS")),
             "parallelism": ("%s: landmark shards x%d + one RCCL all-reduce of the packed reduced camera system (%.0f MB)" % (
                 "weak (871 cameras, 530304 landmarks per GPU)" if weak else "strong (one Venice problem)", world,
@@ -206,7 +208,7 @@ def main():
                 traffic = json.load(open(pmc)).get(args.workload, {}).get("bytes_per_launch")
             except Exception:
                 traffic = None
-        out["roofline"] = {"bound": "mfma", "kernel": "gemm_tn_kernel (MFMA f64 16x16x4 trailing update of the dense factor)",
+        out["roofline"] = {"bound": "mfma", "kernel": "spp::gemm_tn_kernel<128, 128, 32, 32, 0, 1, 1, 16> (MFMA f64 16x16x4 trailing update of the dense factor, 128x128 tiles)",
                            "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
                            "launches_per_solve": int(dom_n), "avg_launch_ms": dom_ms / dom_n,
@@ -222,13 +224,13 @@ def main():
             out["schur_hbm"] = {"achieved": sch_bytes / (sch_ms * 1e-3) * 1e-9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                 "frac": sch_bytes / (sch_ms * 1e-3) * 1e-9 / PEAK_HBM_GBS}
     # ---- CPU baseline: the reference itself (oracle/_ref), same Lambda, bounded sample
-    if not args.no_cpu_baseline and world == 1:
+    if not args.no_cpu_baseline and world == 1 and ctx.info("N_REDUCED") <= 8192:  # the reference's Schur solve is dense: 60000^2 does not fit its path
         try:
             from oracle import spp_oracle as orc
             if orc.have_ref():
                 lam = st.with_vals(d_vals.download())
                 eta = d_eta.download()
-                backend = "schur" if mode == api.MODE_SCHUR else "uberblock"
+                backend = "schur" if schur else "uberblock"
                 rs = orc.RefSolver(backend, lam)
                 secs = []
                 for _ in range(args.cpu_solves):

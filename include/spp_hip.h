@@ -49,6 +49,10 @@ extern "C" {
 #define SPP_MODE_AUTO     0   /* Schur if two block widths with a block-diagonal landmark part, else sparse */
 #define SPP_MODE_SPARSE   1   /* ordering + supernodal block Cholesky on the whole Lambda */
 #define SPP_MODE_SCHUR    2   /* guided Schur complement (landmarks = smaller width) + dense reduced solve */
+#define SPP_MODE_SCHUR_SPARSE 3 /* guided Schur complement, the reduced camera system kept sparse (block-CSC) and
+                                   solved by the supernodal path: CLinearSolver_Schur with a sparse inner solver,
+                                   include/slam/LinearSolver_Schur.h:1844-1853. AUTO picks it beyond 16384 reduced
+                                   scalars (BASELINE config 5: 10k cameras). Single GPU (no landmark shards) for now */
 
 /* spp_create flags */
 #define SPP_FLAG_PROFILE  1   /* record hipEvents around the phases of each solve */
@@ -82,7 +86,7 @@ int spp_analyze(spp_ctx *ctx, int64_t nb, const int64_t *h_col_ptr, const int64_
 int spp_set_shard(spp_ctx *ctx, int rank, int world_size);
 
 /* facts about the analyzed system; unknown keys give SPP_E_BADARG */
-#define SPP_INFO_MODE           0  /* SPP_MODE_SPARSE or SPP_MODE_SCHUR actually chosen */
+#define SPP_INFO_MODE           0  /* SPP_MODE_SPARSE, SPP_MODE_SCHUR or SPP_MODE_SCHUR_SPARSE actually chosen */
 #define SPP_INFO_N              1  /* scalar dimension */
 #define SPP_INFO_NNZB           2  /* stored blocks of Lambda (upper incl. diagonal) */
 #define SPP_INFO_NVALS          3  /* doubles in vals */
@@ -96,7 +100,8 @@ int spp_set_shard(spp_ctx *ctx, int rank, int world_size);
 #define SPP_INFO_SOLVE_BYTES    11 /* algorithmic HBM bytes of one numeric solve */
 #define SPP_INFO_N_SUPERNODES   12
 #define SPP_INFO_N_LEVELS       13
-#define SPP_INFO_S_LD           14 /* leading dimension of the dense S buffer (padded) */
+#define SPP_INFO_S_LD           14 /* leading dimension of the dense S buffer (padded); 0 when S is sparse */
+#define SPP_INFO_S_NNZB         15 /* Schur: stored blocks of the reduced camera system (upper incl. diagonal) */
 int spp_get_info(const spp_ctx *ctx, int what, int64_t *out);
 /* elimination order chosen by the analysis: order[k] = source block column eliminated k-th */
 int spp_get_ordering(const spp_ctx *ctx, int64_t *h_order);

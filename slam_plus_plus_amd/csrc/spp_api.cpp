@@ -231,15 +231,34 @@ int spp_analyze(spp_ctx *ctx, int64_t nb, const int64_t *col_ptr, const int64_t 
 	sparse_release(ctx);
 	int dp, dl;
 	int chosen = mode;
-	if(mode == SPP_MODE_AUTO)
-		chosen = schur_applicable(st, &dp, &dl) ? SPP_MODE_SCHUR : SPP_MODE_SPARSE;
-	SPP_REQUIRE(chosen == SPP_MODE_SCHUR || chosen == SPP_MODE_SPARSE, SPP_E_BADARG, "unknown mode");
+	if(mode == SPP_MODE_AUTO) {
+		chosen = SPP_MODE_SPARSE;
+		if(schur_applicable(st, &dp, &dl)) {
+			// dense reduced system while it is small enough for the MFMA dense factor to win (Venice: 5226),
+			// sparse (supernodal) reduced system beyond: a 10k-camera S is 28.8 GB dense and mostly zeros
+			int64_t n_red = 0;
+			for(int64_t j = 0; j < nb; ++ j)
+				n_red += (dim[j] == dp) ? dp : 0;
+			chosen = (n_red <= 16384 || ctx->shard_world > 1) ? SPP_MODE_SCHUR : SPP_MODE_SCHUR_SPARSE;
+		}
+	}
+	SPP_REQUIRE(chosen == SPP_MODE_SCHUR || chosen == SPP_MODE_SPARSE || chosen == SPP_MODE_SCHUR_SPARSE, SPP_E_BADARG,
+		"unknown mode");
 	SPP_REQUIRE(chosen == SPP_MODE_SCHUR || ctx->shard_world == 1, SPP_E_UNSUPPORTED,
-		"sparse mode does not shard: replicas only (DESIGN.md, multi-GPU)");
+		"only the Schur mode with a dense reduced system shards over landmarks (DESIGN.md, multi-GPU)");
 	ctx->mode = -1;
-	if(chosen == SPP_MODE_SCHUR) {
-		build_schur_plan(ctx);
+	if(chosen == SPP_MODE_SCHUR || chosen == SPP_MODE_SCHUR_SPARSE) {
+		const bool sparse_S = chosen == SPP_MODE_SCHUR_SPARSE;
+		build_schur_plan(ctx, sparse_S);
 		ctx->order.clear();
+		if(sparse_S) {
+			sparse_analyze(ctx, ctx->schur.s_st); // leaves the elimination order of the reduced poses in ctx->order
+			std::vector<int64_t> red = ctx->order;
+			ctx->order.clear();
+			for(size_t i = 0; i < red.size(); ++ i)
+				ctx->order.push_back(ctx->schur.pose_block[red[i]]);
+			chosen = SPP_MODE_SCHUR; // one internal mode; SPP_INFO_MODE reports the variant
+		} else
 		for(size_t i = 0; i < ctx->schur.pose_block.size(); ++ i)
 			ctx->order.push_back(ctx->schur.pose_block[i]);
 		// landmarks are eliminated FIRST in elimination terms; the reference lists them last in its
@@ -248,7 +267,7 @@ int spp_analyze(spp_ctx *ctx, int64_t nb, const int64_t *col_ptr, const int64_t 
 			if(st.dim[j] == ctx->schur.dl)
 				ctx->order.push_back(j);
 	} else
-		sparse_analyze(ctx);
+		sparse_analyze(ctx, ctx->st);
 	ctx->mode = chosen;
 	return SPP_OK;
 	SPP_CATCH(ctx)
@@ -261,7 +280,7 @@ int spp_get_info(const spp_ctx *ctx, int what, int64_t *out)
 	if(ctx->mode < 0 && what != SPP_INFO_NNZB && what != SPP_INFO_NVALS && what != SPP_INFO_N)
 		return SPP_E_STATE;
 	switch(what) {
-	case SPP_INFO_MODE: *out = ctx->mode; break;
+	case SPP_INFO_MODE: *out = (ctx->mode == SPP_MODE_SCHUR && ctx->schur.sparse_S) ? SPP_MODE_SCHUR_SPARSE : ctx->mode; break;
 	case SPP_INFO_N: *out = ctx->st.n; break;
 	case SPP_INFO_NNZB: *out = ctx->st.nnzb; break;
 	case SPP_INFO_NVALS: *out = ctx->st.nvals; break;
@@ -273,9 +292,10 @@ int spp_get_info(const spp_ctx *ctx, int what, int64_t *out)
 	case SPP_INFO_SCHUR_PAIRS: *out = (ctx->mode == SPP_MODE_SCHUR) ? ctx->schur.n_pairs : 0; break;
 	case SPP_INFO_N_OBS: *out = (ctx->mode == SPP_MODE_SCHUR) ? ctx->schur.no : 0; break;
 	case SPP_INFO_SOLVE_BYTES: *out = ctx->solve_bytes; break;
-	case SPP_INFO_N_SUPERNODES: *out = (ctx->mode == SPP_MODE_SPARSE) ? sparse_info(ctx, what) : 0; break;
-	case SPP_INFO_N_LEVELS: *out = (ctx->mode == SPP_MODE_SPARSE) ? sparse_info(ctx, what) : 0; break;
-	case SPP_INFO_S_LD: *out = (ctx->mode == SPP_MODE_SCHUR) ? ctx->schur.ld : 0; break;
+	case SPP_INFO_N_SUPERNODES: *out = ctx->sparse ? sparse_info(ctx, what) : 0; break;
+	case SPP_INFO_N_LEVELS: *out = ctx->sparse ? sparse_info(ctx, what) : 0; break;
+	case SPP_INFO_S_LD: *out = (ctx->mode == SPP_MODE_SCHUR && !ctx->schur.sparse_S) ? ctx->schur.ld : 0; break;
+	case SPP_INFO_S_NNZB: *out = (ctx->mode == SPP_MODE_SCHUR) ? ctx->schur.n_sblk : 0; break;
 	default: return SPP_E_BADARG;
 	}
 	return SPP_OK;
@@ -298,7 +318,7 @@ int spp_schur_buffer_size(const spp_ctx *ctx, int64_t *n_doubles)
 		return SPP_E_BADARG;
 	if(ctx->mode != SPP_MODE_SCHUR)
 		return SPP_E_STATE;
-	*n_doubles = ctx->schur.ld * ctx->schur.ld;
+	*n_doubles = schur_buffer_doubles(ctx);
 	return SPP_OK;
 }
 
@@ -322,6 +342,10 @@ int spp_schur_packed_size(const spp_ctx *ctx, int64_t *n_doubles)
 		return SPP_E_BADARG;
 	if(ctx->mode != SPP_MODE_SCHUR)
 		return SPP_E_STATE;
+	if(ctx->schur.sparse_S) { // already compact: block values | rhs
+		*n_doubles = schur_buffer_doubles(ctx);
+		return SPP_OK;
+	}
 	const int64_t nblk = ctx->schur.ld / DENSE_NB;
 	*n_doubles = (int64_t)DENSE_NB * DENSE_NB * (nblk * (nblk + 1) / 2);
 	return SPP_OK;
@@ -334,7 +358,11 @@ int spp_schur_pack(spp_ctx *ctx, const double *d_S_rhs, double *d_packed)
 	SPP_TRY(ctx)
 	SPP_REQUIRE(ctx->mode == SPP_MODE_SCHUR, SPP_E_STATE, "spp_schur_pack: analyze in Schur mode first");
 	SPP_HIP_CHECK(hipSetDevice(ctx->device));
-	schur_pack(ctx, const_cast<double*>(d_S_rhs), d_packed, true);
+	if(ctx->schur.sparse_S)
+		SPP_HIP_CHECK(hipMemcpyAsync(d_packed, d_S_rhs, (size_t)schur_buffer_doubles(ctx) * sizeof(double),
+			hipMemcpyDeviceToDevice, ctx->stream));
+	else
+		schur_pack(ctx, const_cast<double*>(d_S_rhs), d_packed, true);
 	return SPP_OK;
 	SPP_CATCH(ctx)
 }
@@ -346,7 +374,11 @@ int spp_schur_unpack(spp_ctx *ctx, const double *d_packed, double *d_S_rhs)
 	SPP_TRY(ctx)
 	SPP_REQUIRE(ctx->mode == SPP_MODE_SCHUR, SPP_E_STATE, "spp_schur_unpack: analyze in Schur mode first");
 	SPP_HIP_CHECK(hipSetDevice(ctx->device));
-	schur_pack(ctx, d_S_rhs, const_cast<double*>(d_packed), false);
+	if(ctx->schur.sparse_S)
+		SPP_HIP_CHECK(hipMemcpyAsync(d_S_rhs, d_packed, (size_t)schur_buffer_doubles(ctx) * sizeof(double),
+			hipMemcpyDeviceToDevice, ctx->stream));
+	else
+		schur_pack(ctx, d_S_rhs, const_cast<double*>(d_packed), false);
 	return SPP_OK;
 	SPP_CATCH(ctx)
 }
@@ -378,7 +410,7 @@ int spp_factor_solve_device(spp_ctx *ctx, const double *d_vals, double *d_rhs)
 	if(ctx->mode == SPP_MODE_SCHUR) {
 		SPP_REQUIRE(ctx->shard_world == 1, SPP_E_STATE,
 			"sharded ctx: use spp_schur_form / all-reduce / spp_schur_finish");
-		ctx->schur.S.reserve((size_t)ctx->schur.ld * ctx->schur.ld);
+		ctx->schur.S.reserve((size_t)schur_buffer_doubles(ctx));
 		schur_form(ctx, d_vals, d_rhs, ctx->schur.S.p);
 		ret = schur_finish(ctx, d_vals, ctx->schur.S.p, d_rhs);
 	} else

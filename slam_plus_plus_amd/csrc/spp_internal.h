@@ -79,6 +79,11 @@ struct SchurPlan {
 	int64_t n_pairs = 0;           // sum_p k_p (k_p + 1) / 2
 	int64_t n_items = 0, n_multi = 0; // work items (block chunks) / blocks split over several items
 	bool add_A = true;             // this shard adds A and the pose rhs (rank 0)
+	// reduced camera system kept SPARSE (block-CSC, dp x dp blocks) and solved by the supernodal path:
+	// S buffer = [ s_st.nvals block values | n_red reduced rhs ]
+	bool sparse_S = false;
+	Structure s_st;
+	DevBuf<int64_t> sblk_voff;     // [n_sblk] offset of the S block in the sparse value array
 	// host copies needed later
 	std::vector<int64_t> pose_block; // reduced pose index -> original block column
 	std::vector<int64_t> lm_block;   // owned landmark index -> original block column
@@ -171,11 +176,13 @@ namespace spp {
 
 // ---- spp_symbolic.cpp ----
 void min_degree_order(int64_t nb, const int64_t *col_ptr, const int64_t *row_idx, std::vector<int64_t> &order);
-void build_schur_plan(spp_ctx *ctx);
+void nested_dissection_order(int64_t nb, const int64_t *col_ptr, const int64_t *row_idx, std::vector<int64_t> &order);
+void build_schur_plan(spp_ctx *ctx, bool sparse_S);
+int64_t schur_buffer_doubles(const spp_ctx *ctx); // S | rhs buffer the Schur entry points work on
 bool schur_applicable(const Structure &st, int *dp, int *dl);
 
 // ---- spp_sparse (symbolic on host + numeric on device) ----
-void sparse_analyze(spp_ctx *ctx);
+void sparse_analyze(spp_ctx *ctx, const Structure &st); // plan for `st` (Lambda, or the sparse reduced system)
 int sparse_factor_solve(spp_ctx *ctx, const double *d_vals, double *d_rhs);
 void sparse_release(spp_ctx *ctx);
 int64_t sparse_info(const spp_ctx *ctx, int what);
@@ -195,7 +202,7 @@ void dense_info_reset(spp_ctx *ctx);
 void dense_reserve(spp_ctx *ctx, int64_t nblk); // workspaces for nblk diagonal blocks (call at analyze time)
 int dense_info_fetch(spp_ctx *ctx);
 void dense_set_padding(spp_ctx *ctx, double *d_A, int64_t ld, int64_t n);
-void dense_gemm_tn_sub(spp_ctx *ctx, int64_t m, int64_t n, int64_t k, const double *A, int64_t lda,
+bool dense_gemm_tn_sub(spp_ctx *ctx, int64_t m, int64_t n, int64_t k, const double *A, int64_t lda,
 	const double *B, int64_t ldb, double *C, int64_t ldc, bool upper_only);
 double microbench_copy(spp_ctx *ctx, size_t bytes, int iters);
 double microbench_mfma_f64(spp_ctx *ctx, int iters);

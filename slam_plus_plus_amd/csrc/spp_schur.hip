@@ -129,7 +129,7 @@ void s_accum_kernel(int64_t n_items, const int32_t *__restrict__ item_blk, const
 	const int32_t *__restrict__ item_slot, const int32_t *__restrict__ sblk_i1, const int32_t *__restrict__ sblk_i2,
 	const int64_t *__restrict__ sblk_aoff, const int32_t *__restrict__ pair_a, const int32_t *__restrict__ pair_b,
 	const double *__restrict__ W, const double *__restrict__ Up, const double *__restrict__ vals,
-	int add_A, double *__restrict__ S, int64_t ld, double *__restrict__ partial)
+	int add_A, double *__restrict__ S, int64_t ld, const int64_t *__restrict__ sblk_voff, double *__restrict__ partial)
 {
 	constexpr int NE = DP * DP, BLK = DP * DL, RS = NE + 1;
 	__shared__ double red[SACC_WAVES][64 * RS];
@@ -195,6 +195,10 @@ void s_accum_kernel(int64_t n_items, const int32_t *__restrict__ item_blk, const
 	const int64_t aoff = sblk_aoff[b];
 	if(add_A && aoff >= 0)
 		sum = vals[aoff + lane] + sum; // AddTo_FBS: S = A + W V
+	if(sblk_voff) { // sparse reduced system: dp x dp column-major block in the value array
+		S[sblk_voff[b] + lane] = sum;
+		return;
+	}
 	const int r = lane % DP, c = lane / DP;
 	S[((int64_t)sblk_i1[b] * DP + r) + ((int64_t)sblk_i2[b] * DP + c) * ld] = sum;
 }
@@ -204,7 +208,8 @@ template <int DP>
 __global__ __launch_bounds__(256)
 void s_multi_kernel(int64_t n_multi, const int32_t *__restrict__ multi_blk, const int32_t *__restrict__ multi_ptr,
 	const int32_t *__restrict__ sblk_i1, const int32_t *__restrict__ sblk_i2, const int64_t *__restrict__ sblk_aoff,
-	const double *__restrict__ partial, const double *__restrict__ vals, int add_A, double *__restrict__ S, int64_t ld)
+	const double *__restrict__ partial, const double *__restrict__ vals, int add_A, double *__restrict__ S, int64_t ld,
+	const int64_t *__restrict__ sblk_voff)
 {
 	const int64_t m = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
 	const int lane = threadIdx.x & 63;
@@ -217,6 +222,10 @@ void s_multi_kernel(int64_t n_multi, const int32_t *__restrict__ multi_blk, cons
 	const int64_t aoff = sblk_aoff[b];
 	if(add_A && aoff >= 0)
 		acc = vals[aoff + lane] + acc;
+	if(sblk_voff) {
+		S[sblk_voff[b] + lane] = acc;
+		return;
+	}
 	const int r = lane % DP, c = lane / DP;
 	S[((int64_t)sblk_i1[b] * DP + r) + ((int64_t)sblk_i2[b] * DP + c) * ld] = acc;
 }
@@ -320,8 +329,10 @@ static void schur_form_t(spp_ctx *ctx, const double *d_vals, const double *d_rhs
 	SchurPlan &sp = ctx->schur;
 	hipStream_t s = ctx->stream;
 	const int64_t ld = sp.ld;
+	const int64_t *voff = sp.sparse_S ? sp.sblk_voff.p : nullptr;
+	double *xcol = sp.sparse_S ? S + sp.s_st.nvals : S + sp.n_red * ld; // reduced rhs
 	phase_begin(ctx, SPP_PHASE_SCHUR_INV);
-	SPP_HIP_CHECK(hipMemsetAsync(S, 0, (size_t)ld * ld * sizeof(double), s));
+	SPP_HIP_CHECK(hipMemsetAsync(S, 0, (size_t)schur_buffer_doubles(ctx) * sizeof(double), s));
 	if(sp.nl)
 		hipLaunchKernelGGL((cinv_kernel<DL>), dim3((unsigned)((sp.nl + 255) / 256)), dim3(256), 0, s,
 			sp.nl, sp.lm_coff.p, d_vals, sp.cinv.p);
@@ -333,17 +344,16 @@ static void schur_form_t(spp_ctx *ctx, const double *d_vals, const double *d_rhs
 	if(sp.n_items)
 		hipLaunchKernelGGL((s_accum_kernel<DP, DL>), dim3((unsigned)((sp.n_items + SACC_WAVES - 1) / SACC_WAVES)), dim3(SACC_WAVES * 64), 0, s,
 			sp.n_items, sp.item_blk.p, sp.item_beg.p, sp.item_slot.p, sp.sblk_i1.p, sp.sblk_i2.p, sp.sblk_aoff.p,
-			sp.pair_a.p, sp.pair_b.p, sp.W.p, sp.Up.p, d_vals, sp.add_A ? 1 : 0, S, ld, sp.partial.p);
+			sp.pair_a.p, sp.pair_b.p, sp.W.p, sp.Up.p, d_vals, sp.add_A ? 1 : 0, S, ld, voff, sp.partial.p);
 	if(sp.n_multi)
 		hipLaunchKernelGGL((s_multi_kernel<DP>), dim3((unsigned)((sp.n_multi + 3) / 4)), dim3(256), 0, s,
 			sp.n_multi, sp.multi_blk.p, sp.multi_ptr.p, sp.sblk_i1.p, sp.sblk_i2.p, sp.sblk_aoff.p,
-			sp.partial.p, d_vals, sp.add_A ? 1 : 0, S, ld);
+			sp.partial.p, d_vals, sp.add_A ? 1 : 0, S, ld, voff);
 	phase_end(ctx, SPP_PHASE_SCHUR_GEMM);
 	phase_begin(ctx, SPP_PHASE_SCHUR_RHS);
 	if(sp.nc)
 		hipLaunchKernelGGL((rhs_kernel<DP>), dim3((unsigned)((sp.nc + 3) / 4)), dim3(256), 0, s,
-			sp.nc, sp.cam_ptr.p, sp.cam_obs.p, sp.pose_rbase.p, sp.xw.p, d_rhs, sp.add_A ? 1 : 0,
-			S + sp.n_red * ld);
+			sp.nc, sp.cam_ptr.p, sp.cam_obs.p, sp.pose_rbase.p, sp.xw.p, d_rhs, sp.add_A ? 1 : 0, xcol);
 	phase_end(ctx, SPP_PHASE_SCHUR_RHS);
 	SPP_HIP_CHECK(hipGetLastError());
 }
@@ -355,16 +365,26 @@ static int schur_finish_t(spp_ctx *ctx, const double *d_vals, double *S, double 
 	SchurPlan &sp = ctx->schur;
 	hipStream_t s = ctx->stream;
 	const int64_t ld = sp.ld;
-	phase_begin(ctx, SPP_PHASE_FACTOR);
-	dense_set_padding(ctx, S, ld, sp.n_red);
-	int ret = dense_potrf_upper(ctx, S, sp.n_red, ld, true);
-	phase_end(ctx, SPP_PHASE_FACTOR);
-	if(ret != SPP_OK)
-		return ret;
-	double *xcol = S + sp.n_red * ld;
-	phase_begin(ctx, SPP_PHASE_TRISOLVE);
-	dense_potrs_upper(ctx, S, sp.n_red, ld, xcol);
-	phase_end(ctx, SPP_PHASE_TRISOLVE);
+	double *xcol;
+	if(sp.sparse_S) {
+		// supernodal multifrontal factorization + solves of the sparse reduced camera system (the
+		// reference's CLinearSolver_Schur with a sparse inner solver, LinearSolver_Schur.h:1844-1853)
+		xcol = S + sp.s_st.nvals;
+		const int ret = sparse_factor_solve(ctx, S, xcol);
+		if(ret != SPP_OK)
+			return ret;
+	} else {
+		phase_begin(ctx, SPP_PHASE_FACTOR);
+		dense_set_padding(ctx, S, ld, sp.n_red);
+		int ret = dense_potrf_upper(ctx, S, sp.n_red, ld, true);
+		phase_end(ctx, SPP_PHASE_FACTOR);
+		if(ret != SPP_OK)
+			return ret;
+		xcol = S + sp.n_red * ld;
+		phase_begin(ctx, SPP_PHASE_TRISOLVE);
+		dense_potrs_upper(ctx, S, sp.n_red, ld, xcol);
+		phase_end(ctx, SPP_PHASE_TRISOLVE);
+	}
 	phase_begin(ctx, SPP_PHASE_BACKSUBST);
 	if(sp.nl)
 		hipLaunchKernelGGL((backsubst_kernel<DP, DL>), dim3((unsigned)((sp.nl + 255) / 256)), dim3(256), 0, s,

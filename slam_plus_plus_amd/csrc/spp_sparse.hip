@@ -30,6 +30,7 @@
 #include <numeric>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 namespace spp {
 
@@ -163,9 +164,8 @@ int64_t sparse_info(const spp_ctx *ctx, int what)
 static const int NCLS = 5;
 static const int MID_FRONT_MAX = 384; // padded height up to which ONE workgroup factors a front in place in HBM
 
-void sparse_analyze(spp_ctx *ctx)
+void sparse_analyze(spp_ctx *ctx, const Structure &st)
 {
-	const Structure &st = ctx->st;
 	const int64_t nb = st.nb;
 	sparse_release(ctx);
 	SparsePlan *sp = new SparsePlan;
@@ -174,50 +174,78 @@ void sparse_analyze(spp_ctx *ctx)
 	sp->n = st.n;
 	SPP_REQUIRE(st.n < (int64_t(1) << 31), SPP_E_UNSUPPORTED, "sparse path: scalar dimension exceeds 32-bit indices");
 
-	// ---- 1. fill-reducing order, then postorder of its elimination tree
-	std::vector<int64_t> order0;
-	min_degree_order(nb, st.col_ptr.data(), st.row_idx.data(), order0);
-	std::vector<int64_t> inv(nb);
-	for(int64_t k = 0; k < nb; ++ k)
-		inv[order0[k]] = k;
-	std::vector<std::vector<int32_t> > up;
+	// ---- 1. + 2. fill-reducing order, postorder of its elimination tree, row structure of every row
+	// of R (= column structure of L, children merged upward): rstruct[j] = sorted block columns c > j
+	// with R(j, c) != 0
+	std::vector<int64_t> inv(nb), order(nb);
+	std::vector<std::vector<int32_t> > up, rstruct;
 	std::vector<int32_t> parent, post;
-	permuted_pattern(st, inv, up);
-	etree_of(nb, up, parent);
-	postorder(parent, post);
-	std::vector<int64_t> order(nb);
-	for(int64_t k = 0; k < nb; ++ k)
-		order[k] = order0[post[k]];
-	for(int64_t k = 0; k < nb; ++ k)
-		inv[order[k]] = k;
-	permuted_pattern(st, inv, up);
-	etree_of(nb, up, parent);
-	ctx->order = order;
-
-	// ---- 2. row structure of every row of R (= column structure of L), children merged upward
-	// struct[j] = sorted block columns c > j with R(j, c) != 0
-	std::vector<std::vector<int32_t> > rstruct(nb);
-	{
+	double sym_flops = 0; // sum_j (row count)^2, block level
+	int64_t sym_height = 0; // longest root-to-leaf path of the elimination tree, in block columns
+	auto symbolic = [&](const std::vector<int64_t> &order0) {
+		for(int64_t k = 0; k < nb; ++ k)
+			inv[order0[k]] = k;
+		permuted_pattern(st, inv, up);
+		etree_of(nb, up, parent);
+		postorder(parent, post);
+		for(int64_t k = 0; k < nb; ++ k)
+			order[k] = order0[post[k]];
+		for(int64_t k = 0; k < nb; ++ k)
+			inv[order[k]] = k;
+		permuted_pattern(st, inv, up);
+		etree_of(nb, up, parent);
+		rstruct.assign(nb, std::vector<int32_t>());
 		// entries of A in row j right of the diagonal: from the permuted upper pattern, (a, b) a < b
 		for(int64_t b = 0; b < nb; ++ b)
 			for(size_t q = 0; q < up[b].size(); ++ q)
 				rstruct[up[b][q]].push_back((int32_t)b);
-		std::vector<int32_t> tmp;
+		sym_flops = 0;
+		std::vector<int32_t> depth(nb, 1);
 		for(int64_t j = 0; j < nb; ++ j) {
-			std::vector<int32_t> &s = rstruct[j];
-			std::sort(s.begin(), s.end());
-			s.erase(std::unique(s.begin(), s.end()), s.end());
+			std::vector<int32_t> &rs = rstruct[j];
+			std::sort(rs.begin(), rs.end());
+			rs.erase(std::unique(rs.begin(), rs.end()), rs.end());
+			sym_flops += (double)(rs.size() + 1) * (double)(rs.size() + 1);
 			// push to the parent: struct[parent] U= struct[j] \ {parent}
 			const int32_t p = parent[j];
-			SPP_REQUIRE(p < 0 || (!s.empty() && s[0] == p), SPP_E_HIP, "internal: etree/structure mismatch");
+			SPP_REQUIRE(p < 0 || (!rs.empty() && rs[0] == p), SPP_E_HIP, "internal: etree/structure mismatch");
 			if(p >= 0) {
-				tmp.clear();
-				std::vector<int32_t> &ps = rstruct[p];
 				// ps is not sorted yet (raw A entries): append, it is sorted/uniqued when p is visited
-				ps.insert(ps.end(), s.begin() + 1, s.end());
+				std::vector<int32_t> &ps = rstruct[p];
+				ps.insert(ps.end(), rs.begin() + 1, rs.end());
+				depth[p] = std::max(depth[p], depth[j] + 1);
 			}
 		}
+		sym_height = 0;
+		for(int64_t j = 0; j < nb; ++ j)
+			sym_height = std::max<int64_t>(sym_height, depth[j]);
+	};
+	{
+		// Minimum degree gives the least fill; on chain-like graphs its elimination tree is one long
+		// chain, though, and the level-scheduled kernels then run one small front after the other.
+		// Nested dissection is taken instead when it cuts the tree height by more than 4x at no more
+		// than 3x the block-level flops, or when it is simply better on both counts.
+		// SPP_ORDERING = amd | nd forces one of them.
+		std::vector<int64_t> amd, nd;
+		min_degree_order(nb, st.col_ptr.data(), st.row_idx.data(), amd);
+		symbolic(amd);
+		const char *force = getenv("SPP_ORDERING");
+		const bool want_nd = force ? !strcmp(force, "nd") : (nb >= 256);
+		if(want_nd) {
+			const double f_amd = sym_flops;
+			const int64_t h_amd = sym_height;
+			nested_dissection_order(nb, st.col_ptr.data(), st.row_idx.data(), nd);
+			symbolic(nd);
+			const bool take = force ? true : ((4 * sym_height < h_amd && sym_flops <= 3.0 * f_amd) ||
+				(sym_height < h_amd && sym_flops <= 1.02 * f_amd));
+			if(getenv("SPP_VERBOSE"))
+				fprintf(stderr, "[spp] ordering: amd height %lld flops %.3g | nd height %lld flops %.3g -> %s\n",
+					(long long)h_amd, f_amd, (long long)sym_height, sym_flops, take ? "nd" : "amd");
+			if(!take)
+				symbolic(amd);
+		}
 	}
+	ctx->order = order;
 
 	// ---- 3. fundamental supernodes + relaxed amalgamation of the last child
 	std::vector<int32_t> n_child(nb, 0);
@@ -248,7 +276,7 @@ void sparse_analyze(spp_ctx *ctx)
 		// scalar width / height helpers on current (possibly merged) supernodes
 		std::vector<char> merged_into_next(ns, 0);
 		// process from the leaves: greedy chain merging
-		std::vector<int64_t> cur_w(ns), cur_hbeyond(ns);
+		std::vector<int64_t> cur_w(ns), cur_hbeyond(ns), cur_zeros(ns, 0); // cur_zeros: explicit zeros already bought
 		for(int64_t s = 0; s < ns; ++ s) {
 			int64_t w = 0;
 			for(int32_t c = sn_first[s]; c <= sn_last[s]; ++ c)
@@ -270,9 +298,15 @@ void sparse_analyze(spp_ctx *ctx)
 			const int64_t zeros = ws * (hp - hs_beyond);
 			const int64_t merged_panel = (ws + wp) * (ws + hp);
 			const bool small = (ws + wp) <= 24;
-			if(zeros == 0 || small || (double)zeros <= 0.12 * (double)merged_panel) {
+			// ALL explicit zeros of the merged supernode count (those bought by earlier merges included):
+			// along a chain -- the elimination tree of a banded system -- the newly added zeros alone
+			// always look small next to the growing panel, and the whole chain would collapse into one
+			// dense front
+			const int64_t ztot = zeros + cur_zeros[s] + cur_zeros[s + 1];
+			if(zeros == 0 || small || (double)ztot <= 0.12 * (double)merged_panel) {
 				merged_into_next[s] = 1;
 				cur_w[s + 1] = ws + wp; // the merged supernode takes the parent's slot
+				cur_zeros[s + 1] = ztot;
 			}
 		}
 		for(int64_t s = 0; s < ns; ++ s)

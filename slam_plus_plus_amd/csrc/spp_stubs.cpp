@@ -2,7 +2,7 @@
 #include "spp_internal.h"
 namespace spp {
 #ifndef SPP_HAVE_SPARSE
-void sparse_analyze(spp_ctx *) { throw Error(SPP_E_UNSUPPORTED, "sparse mode not built"); }
+void sparse_analyze(spp_ctx *, const Structure &) { throw Error(SPP_E_UNSUPPORTED, "sparse mode not built"); }
 int sparse_factor_solve(spp_ctx *, const double *, double *) { throw Error(SPP_E_UNSUPPORTED, "sparse mode not built"); }
 void sparse_release(spp_ctx *) {}
 int64_t sparse_info(const spp_ctx *, int) { return 0; }

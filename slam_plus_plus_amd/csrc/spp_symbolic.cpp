@@ -24,6 +24,7 @@ void SchurPlan::release_all()
 	lm_ptr.release(); lm_coff.release(); lm_rbase.release(); obs_pose.release(); obs_lm.release();
 	obs_off.release(); pose_rbase.release(); cam_ptr.release(); cam_obs.release(); item_blk.release();
 	item_beg.release(); item_slot.release(); sblk_i1.release(); sblk_i2.release(); sblk_aoff.release();
+	sblk_voff.release(); s_st = Structure(); sparse_S = false;
 	pair_a.release(); pair_b.release(); multi_blk.release(); multi_ptr.release(); cinv.release();
 	W.release(); Up.release(); xw.release(); partial.release(); S.release();
 	pose_block.clear(); lm_block.clear();
@@ -66,11 +67,18 @@ bool schur_applicable(const Structure &st, int *dp_out, int *dl_out)
 
 static const int PAIR_CHUNK = 2048; // pairs per work item of the S accumulation
 
-void build_schur_plan(spp_ctx *ctx)
+int64_t schur_buffer_doubles(const spp_ctx *ctx)
+{
+	const SchurPlan &sp = ctx->schur;
+	return sp.sparse_S ? sp.s_st.nvals + sp.n_red : sp.ld * sp.ld;
+}
+
+void build_schur_plan(spp_ctx *ctx, bool sparse_S)
 {
 	const Structure &st = ctx->st;
 	SchurPlan &sp = ctx->schur;
 	sp.release_all();
+	sp.sparse_S = sparse_S;
 	int dp, dl;
 	SPP_REQUIRE(schur_applicable(st, &dp, &dl), SPP_E_UNSUPPORTED,
 		"Schur mode needs exactly two block widths ({6,3} or {3,2}) and a block-diagonal landmark part");
@@ -100,7 +108,8 @@ void build_schur_plan(spp_ctx *ctx)
 	sp.add_A = (ctx->shard_rank == 0);
 	sp.n_red = nc * dp;
 	sp.ld = ((sp.n_red + 1 + DENSE_NB - 1) / DENSE_NB) * DENSE_NB; // at least one padding column (rhs)
-	SPP_REQUIRE(sp.ld <= 65536, SPP_E_UNSUPPORTED, "reduced camera system too large for the dense path");
+	SPP_REQUIRE(sparse_S || sp.ld <= 65536, SPP_E_UNSUPPORTED,
+		"reduced camera system too large for the dense path (use SPP_MODE_SCHUR_SPARSE)");
 
 	// ---- observations: every pose-landmark block, sorted by (landmark, pose)
 	struct Obs { int32_t lm, pose; int64_t off; };
@@ -233,6 +242,39 @@ void build_schur_plan(spp_ctx *ctx)
 	const int64_t n_sblk = (int64_t)sblk_i1.size();
 	sp.n_sblk = n_sblk;
 
+	// ---- sparse reduced system: the written blocks of S as an upper block-CSC structure (columns = i2,
+	// rows i1 ascending, diagonal last): the block list above is row-major, a counting sort by column
+	// keeps the rows ascending
+	if(sparse_S) {
+		Structure &ss = sp.s_st;
+		ss.nb = nc;
+		ss.nnzb = n_sblk;
+		ss.dim.assign(nc, dp);
+		ss.base.resize(nc + 1);
+		for(int64_t c = 0; c <= nc; ++ c)
+			ss.base[c] = c * dp;
+		ss.n = nc * dp;
+		ss.col_ptr.assign(nc + 1, 0);
+		for(int64_t b = 0; b < n_sblk; ++ b)
+			++ ss.col_ptr[sblk_i2[b] + 1];
+		for(int64_t c = 0; c < nc; ++ c)
+			ss.col_ptr[c + 1] += ss.col_ptr[c];
+		ss.row_idx.resize(n_sblk);
+		ss.blk_off.resize(n_sblk);
+		std::vector<int64_t> voff(n_sblk), fill(ss.col_ptr.begin(), ss.col_ptr.end() - 1);
+		for(int64_t b = 0; b < n_sblk; ++ b) {
+			const int64_t q = fill[sblk_i2[b]] ++;
+			ss.row_idx[q] = sblk_i1[b];
+			ss.blk_off[q] = q * dp * dp;
+			voff[b] = q * dp * dp;
+		}
+		ss.nvals = n_sblk * dp * dp;
+		for(int64_t c = 0; c < nc; ++ c)
+			SPP_REQUIRE(ss.col_ptr[c + 1] > ss.col_ptr[c] && ss.row_idx[ss.col_ptr[c + 1] - 1] == c, SPP_E_BADARG,
+				"a pose without any diagonal contribution: the reduced system is singular");
+		sp.sblk_voff.upload(voff, s);
+	}
+
 	// ---- work items: chunks of at most PAIR_CHUNK pairs
 	std::vector<int32_t> item_blk, item_beg, item_slot, multi_blk, multi_ptr;
 	int32_t n_slots = 0;
@@ -289,7 +331,8 @@ void build_schur_plan(spp_ctx *ctx)
 	sp.partial.reserve((size_t)std::max<int32_t>(1, n_slots) * dp * dp);
 	SPP_HIP_CHECK(hipStreamSynchronize(s)); // host vectors die here
 
-	dense_reserve(ctx, (sp.n_red + DENSE_NB - 1) / DENSE_NB);
+	if(!sparse_S)
+		dense_reserve(ctx, (sp.n_red + DENSE_NB - 1) / DENSE_NB);
 
 	// ---- accounting (SURVEY 8d "Schur" + "Dense reduced solve")
 	const double n = (double)sp.n_red;
@@ -441,6 +484,214 @@ void min_degree_order(int64_t nb, const int64_t *col_ptr, const int64_t *row_idx
 			if(degree[v] < mindeg)
 				mindeg = degree[v];
 		}
+	}
+}
+
+
+// --------------------------------------------------------------------------------------------------
+// Nested dissection on the block graph (George & Liu's automatic nested dissection): a level
+// structure rooted at a pseudo-peripheral vertex, the smallest level of its middle part as vertex
+// separator (thinned to the vertices that really touch the far side), recursion on the two parts,
+// separator ordered last; subdomains of at most ND_LEAF blocks are ordered by minimum degree.
+// Chain-like graphs (the reduced camera system of a long trajectory, BASELINE config 5) get an
+// elimination tree of logarithmic height instead of the one long chain minimum degree produces, which
+// is what the level-scheduled multifrontal kernels need (ordering).
+// order[k] = block column eliminated k-th.
+// --------------------------------------------------------------------------------------------------
+static const int ND_LEAF = 48;
+
+void nested_dissection_order(int64_t nb, const int64_t *col_ptr, const int64_t *row_idx, std::vector<int64_t> &order)
+{
+	order.assign(nb, -1);
+	if(nb == 0)
+		return;
+	std::vector<std::vector<int32_t> > adj(nb);
+	for(int64_t j = 0; j < nb; ++ j)
+		for(int64_t p = col_ptr[j]; p < col_ptr[j + 1]; ++ p) {
+			const int64_t i = row_idx[p];
+			if(i != j) {
+				adj[i].push_back((int32_t)j);
+				adj[j].push_back((int32_t)i);
+			}
+		}
+	// part[v]: id of the subset v currently belongs to; subsets are processed from a stack, each gets
+	// a target range [lo, hi) of positions in the final order (separator at the end of the range)
+	std::vector<int32_t> part(nb, 0), level(nb, -1), local(nb, -1);
+	struct Task { std::vector<int32_t> verts; int64_t lo; };
+	std::vector<Task> stack;
+	{
+		Task t;
+		t.verts.resize(nb);
+		for(int64_t v = 0; v < nb; ++ v)
+			t.verts[v] = (int32_t)v;
+		t.lo = 0;
+		stack.push_back(std::move(t));
+	}
+	int32_t next_part = 1;
+	std::vector<int32_t> queue;
+	auto bfs = [&](int32_t root, int32_t pid, std::vector<int32_t> &out) { // level structure inside subset pid
+		out.clear();
+		out.push_back(root);
+		level[root] = 0;
+		for(size_t h = 0; h < out.size(); ++ h) {
+			const int32_t v = out[h];
+			for(size_t q = 0; q < adj[v].size(); ++ q) {
+				const int32_t u = adj[v][q];
+				if(part[u] == pid && level[u] < 0) {
+					level[u] = level[v] + 1;
+					out.push_back(u);
+				}
+			}
+		}
+	};
+	while(!stack.empty()) {
+		Task t = std::move(stack.back());
+		stack.pop_back();
+		const int64_t m = (int64_t)t.verts.size();
+		if(m == 0)
+			continue;
+		const int32_t pid = part[t.verts[0]];
+		if(m <= ND_LEAF) {
+			// minimum degree on the induced subgraph (upper pattern in local numbering)
+			for(int64_t q = 0; q < m; ++ q)
+				local[t.verts[q]] = (int32_t)q;
+			std::vector<int64_t> cp(m + 1, 0), ri;
+			for(int64_t q = 0; q < m; ++ q) {
+				const int32_t v = t.verts[q];
+				for(size_t e = 0; e < adj[v].size(); ++ e) {
+					const int32_t u = adj[v][e];
+					if(part[u] == pid && local[u] < q)
+						ri.push_back(local[u]);
+				}
+				std::sort(ri.begin() + cp[q], ri.end());
+				ri.erase(std::unique(ri.begin() + cp[q], ri.end()), ri.end());
+				ri.push_back(q); // diagonal last
+				cp[q + 1] = (int64_t)ri.size();
+			}
+			std::vector<int64_t> lo;
+			min_degree_order(m, cp.data(), ri.data(), lo);
+			for(int64_t q = 0; q < m; ++ q)
+				order[t.lo + q] = t.verts[lo[q]];
+			for(int64_t q = 0; q < m; ++ q) {
+				local[t.verts[q]] = -1;
+				part[t.verts[q]] = -1; // done
+			}
+			continue;
+		}
+		// pseudo-peripheral root: two sweeps
+		bfs(t.verts[0], pid, queue);
+		if((int64_t)queue.size() < m) {
+			// disconnected: split off this component, no separator
+			const int32_t pa = next_part ++;
+			Task a, b;
+			for(size_t q = 0; q < queue.size(); ++ q)
+				part[queue[q]] = pa;
+			for(int64_t q = 0; q < m; ++ q) {
+				const int32_t v = t.verts[q];
+				level[v] = -1;
+				(part[v] == pa ? a : b).verts.push_back(v);
+			}
+			a.lo = t.lo;
+			b.lo = t.lo + (int64_t)a.verts.size();
+			stack.push_back(std::move(a));
+			stack.push_back(std::move(b));
+			continue;
+		}
+		int32_t far = queue.back();
+		for(size_t q = 0; q < queue.size(); ++ q)
+			level[queue[q]] = -1;
+		bfs(far, pid, queue);
+		const int32_t nlev = level[queue.back()] + 1;
+		if(nlev < 3) { // clique-like: no useful separator
+			for(int64_t q = 0; q < m; ++ q) {
+				local[t.verts[q]] = (int32_t)q;
+				level[t.verts[q]] = -1;
+			}
+			std::vector<int64_t> cp(m + 1, 0), ri;
+			for(int64_t q = 0; q < m; ++ q) {
+				const int32_t v = t.verts[q];
+				for(size_t e = 0; e < adj[v].size(); ++ e) {
+					const int32_t u = adj[v][e];
+					if(part[u] == pid && local[u] < q)
+						ri.push_back(local[u]);
+				}
+				std::sort(ri.begin() + cp[q], ri.end());
+				ri.erase(std::unique(ri.begin() + cp[q], ri.end()), ri.end());
+				ri.push_back(q);
+				cp[q + 1] = (int64_t)ri.size();
+			}
+			std::vector<int64_t> lo;
+			min_degree_order(m, cp.data(), ri.data(), lo);
+			for(int64_t q = 0; q < m; ++ q)
+				order[t.lo + q] = t.verts[lo[q]];
+			for(int64_t q = 0; q < m; ++ q) {
+				local[t.verts[q]] = -1;
+				part[t.verts[q]] = -1;
+			}
+			continue;
+		}
+		// level sizes; separator = smallest level whose cumulative position lies in the middle part
+		std::vector<int64_t> lsize(nlev, 0);
+		for(size_t q = 0; q < queue.size(); ++ q)
+			++ lsize[level[queue[q]]];
+		int32_t best = -1;
+		{
+			int64_t below = 0;
+			double best_cost = 0;
+			for(int32_t l = 0; l < nlev; ++ l) {
+				const int64_t above = m - below - lsize[l];
+				if(l > 0 && l + 1 < nlev) {
+					const double bal = (double)std::min(below, above) / (double)std::max<int64_t>(1, std::max(below, above));
+					// small separators, balanced parts: separator size penalized by imbalance
+					const double cost = (double)lsize[l] * (1.0 + 2.0 * (1.0 - bal) * (1.0 - bal) * 4.0);
+					if(bal >= 0.25 && (best < 0 || cost < best_cost)) {
+						best = l;
+						best_cost = cost;
+					}
+				}
+				below += lsize[l];
+			}
+			if(best < 0)
+				best = nlev / 2;
+		}
+		// near part: levels < best; far part: levels > best; separator vertices without a neighbour in
+		// level best + 1 move to the near part
+		const int32_t pa = next_part ++, pb = next_part ++;
+		Task a, b;
+		std::vector<int32_t> sep;
+		for(size_t q = 0; q < queue.size(); ++ q) {
+			const int32_t v = queue[q];
+			if(level[v] < best)
+				a.verts.push_back(v);
+			else if(level[v] > best)
+				b.verts.push_back(v);
+			else {
+				bool touches = false;
+				for(size_t e = 0; e < adj[v].size() && !touches; ++ e) {
+					const int32_t u = adj[v][e];
+					touches = part[u] == pid && level[u] == best + 1;
+				}
+				if(touches)
+					sep.push_back(v);
+				else
+					a.verts.push_back(v);
+			}
+		}
+		for(size_t q = 0; q < a.verts.size(); ++ q)
+			part[a.verts[q]] = pa;
+		for(size_t q = 0; q < b.verts.size(); ++ q)
+			part[b.verts[q]] = pb;
+		for(size_t q = 0; q < queue.size(); ++ q)
+			level[queue[q]] = -1;
+		a.lo = t.lo;
+		b.lo = t.lo + (int64_t)a.verts.size();
+		const int64_t slo = b.lo + (int64_t)b.verts.size();
+		for(size_t q = 0; q < sep.size(); ++ q) {
+			order[slo + (int64_t)q] = sep[q];
+			part[sep[q]] = -1;
+		}
+		stack.push_back(std::move(a));
+		stack.push_back(std::move(b));
 	}
 }
 

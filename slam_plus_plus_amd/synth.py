@@ -239,6 +239,9 @@ CONFIGS = {
     "ba_small": lambda: ba_problem(30, 1500, 7000, 30, heavy_tail=True, spread=0.2, name="ba_small"),
     "ba_interleaved": lambda: ba_problem(25, 900, 4000, 25, heavy_tail=True, interleave=True, spread=0.3, name="ba_interleaved"),
     "ba_medium": lambda: ba_problem(150, 20000, 100000, 150, heavy_tail=True, name="ba_medium"),
+    # a long camera trajectory: every point is seen from a narrow window of cameras, the reduced camera
+    # system is banded (the shape of BASELINE config 5 at a size the CPU reference finishes in seconds)
+    "ba_banded": lambda: ba_problem(600, 30000, 150000, 600, heavy_tail=False, spread=0.01, name="ba_banded"),
     "se2_small": lambda: se2_problem(300, 150, 12, name="se2_small"),
     "se3_small": lambda: se3_problem(8, 12, 13, name="se3_small"),
 }
