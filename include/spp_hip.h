@@ -106,6 +106,16 @@ int spp_get_info(const spp_ctx *ctx, int what, int64_t *out);
 /* elimination order chosen by the analysis: order[k] = source block column eliminated k-th */
 int spp_get_ordering(const spp_ctx *ctx, int64_t *h_order);
 
+/* Fill-reducing block ordering of an upper block pattern, host only (no context, no GPU): the job of
+ * CMatrixOrdering::p_BlockOrdering (reference src/slam/OrderingMagic.cpp:701, live path :900-1031:
+ * A + A^T block pattern -> AMD). order[k] = block column eliminated k-th (the reference returns the
+ * inverse of this). SPP_ORDER_AMD: approximate minimum degree (quotient graph); SPP_ORDER_ND: nested
+ * dissection on BFS level structures with minimum-degree leaves (logarithmic tree height on
+ * chain-like graphs). The analysis picks between the two itself (ordering). */
+#define SPP_ORDER_AMD 0
+#define SPP_ORDER_ND  1
+int spp_block_ordering(int64_t nb, const int64_t *col_ptr, const int64_t *row_idx, int method, int64_t *h_order);
+
 /* ---- numeric: host-pointer entry points (what the header adapter calls) ----------------------------
  * replaces: Solve_PosDef_Blocky (LinearSolver_UberBlock.h:312-426; LinearSolver_Schur.h:1623-1935)
  * and Solve_PosDef (LinearSolver_UberBlock.h:143-258). h_vals holds the blocks at the blk_off

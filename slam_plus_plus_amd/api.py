@@ -32,7 +32,7 @@ EXPORTS = [
     "spp_schur_packed_size", "spp_schur_pack", "spp_schur_unpack",
     "spp_assemble_analyze", "spp_assemble_get_structure", "spp_assemble_device", "spp_device_malloc",
     "spp_device_free", "spp_memcpy_h2d", "spp_memcpy_d2h", "spp_memcpy_d2d", "spp_get_phase_ms", "spp_get_dominant_kernel",
-    "spp_microbench_copy", "spp_microbench_mfma_f64", "spp_microbench_ctile", "spp_dense_potrf_upper", "spp_dense_posv",
+    "spp_microbench_copy", "spp_microbench_mfma_f64", "spp_microbench_ctile", "spp_block_ordering", "spp_dense_potrf_upper", "spp_dense_posv",
     "spp_dense_gemm_tn_sub", "spp_version",
 ]
 
@@ -87,6 +87,7 @@ def load_library():
         "spp_microbench_copy": (cint, [vp, ctypes.c_size_t, cint, _c_f64p]),
         "spp_microbench_mfma_f64": (cint, [vp, cint, _c_f64p]),
         "spp_microbench_ctile": (cint, [vp, cint, cint, _c_f64p]),
+        "spp_block_ordering": (cint, [ctypes.c_int64, vp, vp, cint, vp]),
         "spp_dense_potrf_upper": (cint, [vp, vp, i64, i64]),
         "spp_dense_posv": (cint, [vp, vp, i64, i64, vp]),
         "spp_dense_gemm_tn_sub": (cint, [vp, i64, i64, i64, vp, i64, vp, i64, vp, i64]),
@@ -102,6 +103,22 @@ def load_library():
 
 def _ptr(a):
     return a.ctypes.data_as(ctypes.c_void_p)
+
+
+ORDER_AMD, ORDER_ND = 0, 1
+
+
+def block_ordering(lam, method=ORDER_AMD):
+    """Host-only fill-reducing ordering of a BlockCSC / Structure pattern (spp_block_ordering): the
+    counterpart of CMatrixOrdering::p_BlockOrdering, src/slam/OrderingMagic.cpp:701. No GPU needed."""
+    lib = load_library()
+    col_ptr = np.ascontiguousarray(lam.col_ptr, dtype=np.int64)
+    row_idx = np.ascontiguousarray(lam.row_idx, dtype=np.int64)
+    out = np.empty(lam.nb, dtype=np.int64)
+    code = lib.spp_block_ordering(lam.nb, _ptr(col_ptr), _ptr(row_idx), method, _ptr(out))
+    if code != 0:
+        raise SppError("spp_block_ordering failed: %d" % code)
+    return out
 
 
 class DeviceArray:

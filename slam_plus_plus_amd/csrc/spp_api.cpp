@@ -312,6 +312,30 @@ int spp_get_ordering(const spp_ctx *ctx, int64_t *h_order)
 	return SPP_OK;
 }
 
+int spp_block_ordering(int64_t nb, const int64_t *col_ptr, const int64_t *row_idx, int method, int64_t *h_order)
+{
+	if(nb <= 0 || !col_ptr || !row_idx || !h_order || (method != SPP_ORDER_AMD && method != SPP_ORDER_ND))
+		return SPP_E_BADARG;
+	try {
+		for(int64_t j = 0; j < nb; ++ j)
+			for(int64_t p = col_ptr[j]; p < col_ptr[j + 1]; ++ p)
+				if(row_idx[p] < 0 || row_idx[p] > j)
+					return SPP_E_BADARG; // upper triangle only
+		std::vector<int64_t> order;
+		if(method == SPP_ORDER_AMD)
+			min_degree_order(nb, col_ptr, row_idx, order);
+		else
+			nested_dissection_order(nb, col_ptr, row_idx, order);
+		for(int64_t k = 0; k < nb; ++ k)
+			h_order[k] = order[k];
+		return SPP_OK;
+	} catch(const std::bad_alloc &) {
+		return SPP_E_NOMEM;
+	} catch(...) {
+		return SPP_E_HIP;
+	}
+}
+
 int spp_schur_buffer_size(const spp_ctx *ctx, int64_t *n_doubles)
 {
 	if(!ctx || !n_doubles)
