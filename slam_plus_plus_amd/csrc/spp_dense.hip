@@ -187,7 +187,14 @@ static void launch_gemm(hipStream_t s, int64_t M, int64_t N, int K, const double
 	dim3 block((BM / WM) * (BN / WN) * 64);
 	if(!grid.x || !grid.y)
 		return;
-	const size_t lds = (size_t)(BM + BN) * (BKT + 2) * sizeof(double);
+	// SPP_GEMM_LDS_PAD: extra dynamic LDS per workgroup = an occupancy limiter (e.g. 49152 leaves one
+	// 1024-thread workgroup per CU, so that the chain kernels of the other stream find wave slots)
+	static size_t pad = (size_t)-1;
+	if(pad == (size_t)-1) {
+		const char *e = getenv("SPP_GEMM_LDS_PAD");
+		pad = e ? (size_t)atol(e) : 0;
+	}
+	const size_t lds = (size_t)(BM + BN) * (BKT + 2) * sizeof(double) + pad;
 	static bool attr = false;
 	if(!attr && lds > 65536) {
 		SPP_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tn_kernel<BM, BN, WM, WN, MODE, DEPTH, MINW, BKT>,
@@ -698,6 +705,11 @@ void dense_factor_steps(spp_ctx *ctx, double *d_A, int64_t ld, int64_t n, int64_
 	ensure_dense_work(ctx, nsteps);
 	hipStream_t s = ctx->stream, s2 = ctx->dense.aux;
 	hipEvent_t evA = ctx->dense.ev[0], evB = ctx->dense.ev[1];
+	static int64_t trsm_shared_above = -1;
+	if(trsm_shared_above < 0) {
+		const char *e = getenv("SPP_TRSM_SHARED_ABOVE");
+		trsm_shared_above = e ? atol(e) : (int64_t(1) << 40);
+	}
 	auto potrf_and_panel = [&](hipStream_t st, int64_t k) {
 		const int64_t k0 = k * NB;
 		const int n_valid = (int)((n - k0 < NB) ? (n - k0) : NB);
@@ -705,9 +717,19 @@ void dense_factor_steps(spp_ctx *ctx, double *d_A, int64_t ld, int64_t n, int64_
 		hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(POTRF_THREADS), POTRF_LDS_DOUBLES * sizeof(double), st,
 			d_A + k0 + k0 * ld, ld, n_valid, (has_rhs && n_valid < NB) ? 1 : 0, tinv, ctx->dense.info.p, k0);
 		const int64_t c1 = k0 + NB;
-		if(c1 < ncols) // panel: R_kj = Tinv^T S_kj in place (A = tinv: 128 x 128; B = C = S[k0.., c1..])
-			launch_gemm_staged<128, 16, 32, 16, 1>(st, NB, ncols - c1, NB, tinv, NB, d_A + k0 + c1 * ld, ld,
-				d_A + k0 + c1 * ld, ld, false);
+		if(c1 < ncols) { // panel: R_kj = Tinv^T S_kj in place (A = tinv: 128 x 128; B = C = S[k0.., c1..])
+			// While the bulk update of the previous step fills the chip (large trailing matrix) the fully
+			// staged kernel -- 150 KB of LDS per workgroup -- only gets CUs as they drain completely and
+			// finishes with the bulk update, delaying the next one. The slab-pipelined kernel (23 KB, 4
+			// waves) shares CUs with the update's workgroups. The staged one has the lower latency when
+			// the chain is what bounds the step (small trailing matrix).
+			if(ncols - c1 >= trsm_shared_above)
+				launch_gemm<128, 32, 32, 32, 1>(st, NB, ncols - c1, NB, tinv, NB, d_A + k0 + c1 * ld, ld,
+					d_A + k0 + c1 * ld, ld, false);
+			else
+				launch_gemm_staged<128, 16, 32, 16, 1>(st, NB, ncols - c1, NB, tinv, NB, d_A + k0 + c1 * ld, ld,
+					d_A + k0 + c1 * ld, ld, false);
+		}
 	};
 	// Steps are processed in PAIRS: the bulk update applies two row panels at once (K = 256), which
 	// halves the read-modify-write traffic of the trailing matrix per flop (the K = 128 update sits on
@@ -728,10 +750,12 @@ void dense_factor_steps(spp_ctx *ctx, double *d_A, int64_t ld, int64_t n, int64_
 	// pairing pays once the bulk update is shorter than the serial chain (it then hides anyway and the
 	// pair saves one cross-stream hand-off); while the trailing matrix is large the single-step schedule
 	// overlaps better. SPP_PAIR_BELOW = trailing rows below which steps are paired.
-	static int64_t pair_below = -1;
+	static int64_t pair_below = -1, pair_above = -1;
 	if(pair_below < 0) {
 		const char *e = getenv("SPP_PAIR_BELOW");
 		pair_below = e ? atol(e) : 0; // measured on Venice-871: pairing raises the update kernel's TFLOP/s but never the wall time
+		e = getenv("SPP_PAIR_ABOVE");
+		pair_above = e ? atol(e) : (int64_t(1) << 40); // pair while the trailing matrix is LARGER than this (bulk-bound phase)
 	}
 	static int eva_early = -1;
 	if(eva_early < 0) {
@@ -740,7 +764,7 @@ void dense_factor_steps(spp_ctx *ctx, double *d_A, int64_t ld, int64_t n, int64_
 	}
 	for(int64_t k = 0; k < nsteps;) {
 		const int64_t k0 = k * NB, c1 = k0 + NB, c2 = c1 + NB, c3 = c2 + NB;
-		const int npan = (rows - c1 < pair_below && k + 1 < nsteps) ? 2 : 1;
+		const int npan = ((rows - c1 < pair_below || rows - c1 > pair_above) && k + 1 < nsteps) ? 2 : 1;
 		if(c1 >= ncols || rows - c1 <= 0)
 			break;
 		// A single-panel bulk update needs only row panel k (complete at this point of the chain stream)

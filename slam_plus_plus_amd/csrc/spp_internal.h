@@ -97,9 +97,13 @@ struct SchurPlan {
 	DevBuf<int64_t> pose_rbase;    // [nc] scalar offset of the pose in rhs
 	DevBuf<int32_t> cam_ptr;       // [nc+1] obs list per pose (ascending landmark)
 	DevBuf<int32_t> cam_obs;       // [no]
+	DevBuf<int32_t> obs_wpos;      // [no] position of the observation in the per-pose (camera-major) lists:
+	                               //      W, Up and xw are stored camera-major (locality of the S accumulation)
 	// S accumulation work items
 	DevBuf<int32_t> item_blk;      // [n_items] S block id
-	DevBuf<int32_t> item_beg;      // [n_items+1] pair range
+	DevBuf<int32_t> item_beg, item_end; // [n_items] pair range (items are ordered by camera tiles, not by block)
+	DevBuf<int32_t> xcd_beg;       // [9] item range of each XCD (equal work, not equal counts)
+	int32_t xcd_max_items = 0;     // longest of those ranges
 	DevBuf<int32_t> item_slot;     // [n_items] -1: writes S directly, else partial slot
 	DevBuf<int32_t> sblk_i1, sblk_i2; // [n_sblk]
 	DevBuf<int64_t> sblk_aoff;     // [n_sblk] offset of the A block in vals or -1
@@ -108,8 +112,8 @@ struct SchurPlan {
 	DevBuf<int32_t> multi_ptr;     // [n_multi+1] slot range
 	// numeric workspaces
 	DevBuf<double> cinv;           // [nl * dl*dl]   -(C^-1)
-	DevBuf<double> W;              // [no * dp*dl]   -U C^-1
-	DevBuf<double> Up;             // [no * dp*dl]   U packed in obs order
+	DevBuf<double> W;              // [no * dp*dl]   -U C^-1, camera-major
+	DevBuf<double> Up;             // [no * dp*dl]   U packed, camera-major
 	DevBuf<double> xw;             // [no * dp]      W l per observation
 	DevBuf<double> partial;        // [slots * dp*dp]
 	DevBuf<double> S;              // [ld*ld + ld] when the caller does not supply the buffer

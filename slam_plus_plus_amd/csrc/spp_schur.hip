@@ -59,20 +59,11 @@ void cinv_kernel(int64_t nl, const int64_t *__restrict__ lm_coff, const double *
 	}
 }
 
-// ---- W = U (-C^-1), packed U, W l : one thread per observation ------------------------------------
+// pose-landmark block of Lambda as DP x DL column-major; (offset << 1) | transposed flag
 template <int DP, int DL>
-__global__ __launch_bounds__(256)
-void obs_kernel(int64_t no, const int32_t *__restrict__ obs_lm, const int64_t *__restrict__ obs_off,
-	const int64_t *__restrict__ lm_rbase, const double *__restrict__ vals, const double *__restrict__ rhs,
-	const double *__restrict__ cinv, double *__restrict__ W, double *__restrict__ Up, double *__restrict__ xw)
+__device__ __forceinline__ void load_U(const double *__restrict__ vals, int64_t oo, double *U)
 {
-	const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if(a >= no)
-		return;
-	const int32_t l = obs_lm[a];
-	const int64_t oo = obs_off[a];
 	const double *src = vals + (oo >> 1);
-	double U[DP * DL];
 	if(oo & 1) { // stored transposed (landmark id < pose id): DL x DP column-major
 #pragma unroll
 		for(int r = 0; r < DP; ++ r)
@@ -84,6 +75,22 @@ void obs_kernel(int64_t no, const int32_t *__restrict__ obs_lm, const int64_t *_
 		for(int e = 0; e < DP * DL; ++ e)
 			U[e] = src[e];
 	}
+}
+
+// ---- W = U (-C^-1), packed U, W l : one thread per observation ------------------------------------
+template <int DP, int DL>
+__global__ __launch_bounds__(256)
+void obs_kernel(int64_t no, const int32_t *__restrict__ obs_lm, const int64_t *__restrict__ obs_off,
+	const int64_t *__restrict__ lm_rbase, const double *__restrict__ vals, const double *__restrict__ rhs,
+	const double *__restrict__ cinv, const int32_t *__restrict__ obs_wpos, double *__restrict__ W,
+	double *__restrict__ Up, double *__restrict__ xw)
+{
+	const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if(a >= no)
+		return;
+	const int32_t l = obs_lm[a];
+	double U[DP * DL];
+	load_U<DP, DL>(vals, obs_off[a], U);
 	double Ci[DL * DL];
 #pragma unroll
 	for(int e = 0; e < DL * DL; ++ e)
@@ -96,7 +103,8 @@ void obs_kernel(int64_t no, const int32_t *__restrict__ obs_lm, const int64_t *_
 #pragma unroll
 	for(int r = 0; r < DP; ++ r)
 		Wl[r] = 0;
-	double *wo = W + a * DP * DL, *uo = Up + a * DP * DL;
+	const int64_t wp = obs_wpos[a]; // camera-major slot of this observation
+	double *wo = W + wp * DP * DL, *uo = Up + wp * DP * DL;
 #pragma unroll
 	for(int q = 0; q < DL; ++ q)
 #pragma unroll
@@ -111,81 +119,141 @@ void obs_kernel(int64_t no, const int32_t *__restrict__ obs_lm, const int64_t *_
 		}
 #pragma unroll
 	for(int r = 0; r < DP; ++ r)
-		xw[a * DP + r] = Wl[r];
+		xw[wp * DP + r] = Wl[r];
 }
 
 // ---- S block accumulation: one wave per work item -------------------------------------------------
-// Each LANE takes whole pairs (a, b) of the item's list (lane, lane + 64, ...): 2 x 9 independent
-// 16-byte loads fetch W_a and U_b, 108 FMAs form the DP x DP outer product sum W_a U_b^T in
-// registers. The 64 partial blocks are then summed IN LANE ORDER through LDS by DP*DP lanes, so for
-// lists of up to 64 pairs (the common case) the additions happen in exactly the order of the pair
-// list (= ascending landmark = the reference's order); longer lists add lane-strided partial sums.
-// No atomics: bit-reproducible.
-constexpr int SACC_WAVES = 2; // waves (items) per workgroup: 2 x 64 x (DP*DP+1) doubles of LDS
+// Each LANE takes whole pairs (a, b) of the item's list (lane, lane + 64, ...) and forms the DP x DP
+// outer product sum W_a U_b^T in registers (108 FMAs per pair). The blocks are NOT fetched by the lane
+// that consumes them: a lane-per-block gather makes every load instruction touch 64 different cache
+// lines and the kernel was bound by the CU's address/tag path at 13 % VALU utilization. Instead the
+// wave fetches the blocks cooperatively -- DP*DL/2 consecutive lanes read the 16-byte pieces of one
+// block, 7 blocks (14 lines) per instruction -- into an LDS image [pair][19 doubles] (the odd stride
+// makes the per-lane ds_read_b64 of the consumer conflict-free), from which every lane then reads its
+// own pair. The 64 partial blocks are summed IN LANE ORDER through LDS, so for lists of up to 64 pairs
+// (the common case) the additions happen in exactly the order of the pair list (= ascending landmark
+// = the reference's order); longer lists add lane-strided partial sums. No atomics: bit-reproducible.
+constexpr int SACC_WAVES = 4; // waves (items) per workgroup
 
 template <int DP, int DL>
 __global__ __launch_bounds__(SACC_WAVES * 64)
 void s_accum_kernel(int64_t n_items, const int32_t *__restrict__ item_blk, const int32_t *__restrict__ item_beg,
-	const int32_t *__restrict__ item_slot, const int32_t *__restrict__ sblk_i1, const int32_t *__restrict__ sblk_i2,
+	const int32_t *__restrict__ item_end, const int32_t *__restrict__ xcd_beg, const int32_t *__restrict__ item_slot,
+	const int32_t *__restrict__ sblk_i1, const int32_t *__restrict__ sblk_i2,
 	const int64_t *__restrict__ sblk_aoff, const int32_t *__restrict__ pair_a, const int32_t *__restrict__ pair_b,
 	const double *__restrict__ W, const double *__restrict__ Up, const double *__restrict__ vals,
 	int add_A, double *__restrict__ S, int64_t ld, const int64_t *__restrict__ sblk_voff, double *__restrict__ partial)
 {
-	constexpr int NE = DP * DP, BLK = DP * DL, RS = NE + 1;
-	__shared__ double red[SACC_WAVES][64 * RS];
+	constexpr int NE = DP * DP, BLK = DP * DL;
+	constexpr int PCS = (BLK + 1) / 2;          // 16-byte pieces per block (the last one half used when BLK is odd)
+	constexpr int PPI = 64 / PCS;               // blocks (pairs) fetched per wave instruction
+	constexpr int NG = (64 + PPI - 1) / PPI;    // instructions per operand and round
+	constexpr int ST = (2 * PCS) | 1;           // LDS stride of one block image in doubles (odd)
+	constexpr int RS = (NE + 1) / 2 + 1;        // row stride of the reduction image
+	static_assert(2 * 64 * ST >= 64 * RS, "the reduction image reuses the staging area");
+	__shared__ double lds[SACC_WAVES][2 * 64 * ST];
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	const int64_t item = (int64_t)blockIdx.x * SACC_WAVES + wave;
-	if(item >= n_items)
+	// workgroups go round-robin over the 8 XCDs: XCD x works through its own contiguous range of the
+	// items (equal work per range), so that the camera segments of a tile of blocks are fetched into
+	// ONE L2 (gridDim.x is a multiple of 8)
+	const int x = blockIdx.x & 7;
+	const int64_t item = xcd_beg[x] + (int64_t)(blockIdx.x >> 3) * SACC_WAVES + wave;
+	if(item >= xcd_beg[x + 1])
 		return; // whole wave
-	const int32_t beg = item_beg[item], end = item_beg[item + 1];
+	double *sw = lds[wave], *su = sw + 64 * ST, *rw = sw;
+	const int32_t beg = item_beg[item], end = item_end[item];
+	const int my_pair = lane / PCS, my_piece = lane % PCS; // role in the cooperative fetch (lanes >= PPI * PCS idle)
 	double acc[NE];
 #pragma unroll
 	for(int e = 0; e < NE; ++ e)
 		acc[e] = 0;
-	for(int32_t q = beg + lane; q < end; q += 64) {
-		const double *wp = W + (int64_t)pair_a[q] * BLK, *up = Up + (int64_t)pair_b[q] * BLK;
-		double w[BLK], u[BLK];
-		if((BLK & 1) == 0) {
+	for(int32_t q0 = beg; q0 < end; q0 += 64) {
+		const int32_t q = q0 + lane;
+		const int32_t pa = (q < end) ? pair_a[q] : -1, pb = (q < end) ? pair_b[q] : -1;
+		// ---- cooperative fetch of up to 64 W and 64 U blocks into the LDS images
+		const int nround = (end - q0 < 64) ? end - q0 : 64;
+		double2 tw[NG], tu[NG];
 #pragma unroll
-			for(int e = 0; e < BLK; e += 2) {
-				const double2 tw = *(const double2*)(wp + e), tu = *(const double2*)(up + e);
-				w[e] = tw.x; w[e + 1] = tw.y;
-				u[e] = tu.x; u[e + 1] = tu.y;
-			}
-		} else {
-#pragma unroll
-			for(int e = 0; e < BLK; ++ e) {
-				w[e] = wp[e];
-				u[e] = up[e];
-			}
+		for(int g = 0; g < NG; ++ g) {
+			const int p = g * PPI + my_pair; // pair of this round served by this lane
+			const int32_t ia = __shfl(pa, p & 63), ib = __shfl(pb, p & 63);
+			const bool on = my_pair < PPI && p < nround;
+			tw[g] = on ? *(const double2*)(W + (int64_t)ia * BLK + 2 * my_piece) : make_double2(0, 0);
+			tu[g] = on ? *(const double2*)(Up + (int64_t)ib * BLK + 2 * my_piece) : make_double2(0, 0);
 		}
 #pragma unroll
-		for(int c = 0; c < DP; ++ c)
-#pragma unroll
-			for(int r = 0; r < DP; ++ r) {
-				double s = 0;
-#pragma unroll
-				for(int t = 0; t < DL; ++ t)
-					s += w[r + DP * t] * u[c + DP * t];
-				acc[r + DP * c] += s;
+		for(int g = 0; g < NG; ++ g) {
+			const int p = g * PPI + my_pair;
+			if(my_pair < PPI && p < 64) {
+				sw[p * ST + 2 * my_piece] = tw[g].x;
+				sw[p * ST + 2 * my_piece + 1] = tw[g].y;
+				su[p * ST + 2 * my_piece] = tu[g].x;
+				su[p * ST + 2 * my_piece + 1] = tu[g].y;
 			}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		// ---- every lane: its own pair out of LDS
+		if(q < end) {
+			double w[BLK], u[BLK];
+#pragma unroll
+			for(int e = 0; e < BLK; ++ e) {
+				w[e] = sw[lane * ST + e];
+				u[e] = su[lane * ST + e];
+			}
+#pragma unroll
+			for(int c = 0; c < DP; ++ c)
+#pragma unroll
+				for(int r = 0; r < DP; ++ r) {
+					double sp = 0;
+#pragma unroll
+					for(int t = 0; t < DL; ++ t)
+						sp += w[r + DP * t] * u[c + DP * t];
+					acc[r + DP * c] += sp;
+				}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
 	}
 	int nact = end - beg;
 	if(nact > 64)
 		nact = 64;
-	double *rw = red[wave];
-	if(lane < nact) {
+	// in-order reduction through LDS in two halves of the block
+	double sum = 0;
 #pragma unroll
-		for(int e = 0; e < NE; ++ e)
-			rw[lane * RS + e] = acc[e];
+	for(int h = 0; h < 2; ++ h) {
+		constexpr int H0 = (NE + 1) / 2;
+		const int e0 = h ? H0 : 0, ne = h ? NE - H0 : H0;
+		if(lane < nact) {
+#pragma unroll
+			for(int e = 0; e < H0; ++ e)
+				if(e < ne)
+					rw[lane * RS + e] = acc[e0 + e];
+		}
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		if(lane >= e0 && lane < e0 + ne) { // lane e owns element e of the block
+			const int e = lane - e0;
+			double sacc = 0; // strictly in lane order; the loads of 8 partial blocks are in flight together
+			int l = 0;
+			for(; l + 8 <= nact; l += 8) {
+				double t[8];
+#pragma unroll
+				for(int u = 0; u < 8; ++ u)
+					t[u] = rw[(l + u) * RS + e];
+#pragma unroll
+				for(int u = 0; u < 8; ++ u)
+					sacc += t[u];
+			}
+			for(; l < nact; ++ l)
+				sacc += rw[l * RS + e];
+			sum = sacc;
+		}
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
 	}
-	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-	__builtin_amdgcn_wave_barrier();
 	if(lane >= NE)
 		return;
-	double sum = 0;
-	for(int l = 0; l < nact; ++ l)
-		sum += rw[l * RS + lane];
 	const int32_t b = item_blk[item];
 	const int32_t slot = item_slot[item];
 	if(slot >= 0) {
@@ -246,7 +314,7 @@ void rhs_kernel(int64_t nc, const int32_t *__restrict__ cam_ptr, const int32_t *
 	for(int r = 0; r < DP; ++ r)
 		s[r] = 0;
 	for(int32_t q = cam_ptr[i] + lane; q < cam_ptr[i + 1]; q += 64) {
-		const double *x = xw + (int64_t)cam_obs[q] * DP;
+		const double *x = xw + (int64_t)q * DP; // xw is camera-major: the pose's list is contiguous
 #pragma unroll
 		for(int r = 0; r < DP; ++ r)
 			s[r] += x[r];
@@ -273,8 +341,8 @@ void rhs_kernel(int64_t nc, const int32_t *__restrict__ cam_ptr, const int32_t *
 template <int DP, int DL>
 __global__ __launch_bounds__(256)
 void backsubst_kernel(int64_t nl, const int32_t *__restrict__ lm_ptr, const int32_t *__restrict__ obs_pose,
-	const int64_t *__restrict__ lm_rbase, const double *__restrict__ Up, const double *__restrict__ cinv,
-	const double *__restrict__ dx, double *__restrict__ rhs)
+	const int64_t *__restrict__ lm_rbase, const int64_t *__restrict__ obs_off, const double *__restrict__ vals,
+	const double *__restrict__ cinv, const double *__restrict__ dx, double *__restrict__ rhs)
 {
 	const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if(l >= nl)
@@ -285,7 +353,8 @@ void backsubst_kernel(int64_t nl, const int32_t *__restrict__ lm_ptr, const int3
 	for(int q = 0; q < DL; ++ q)
 		t[q] = -rhs[rb + q]; // v_l = -v_l, LinearSolver_Schur.h:1867
 	for(int32_t a = lm_ptr[l]; a < lm_ptr[l + 1]; ++ a) {
-		const double *u = Up + (int64_t)a * DP * DL;
+		double u[DP * DL]; // U of this observation straight from Lambda (a landmark's blocks are contiguous there)
+		load_U<DP, DL>(vals, obs_off[a], u);
 		const double *d = dx + (int64_t)obs_pose[a] * DP;
 		double dv[DP];
 #pragma unroll
@@ -338,12 +407,12 @@ static void schur_form_t(spp_ctx *ctx, const double *d_vals, const double *d_rhs
 			sp.nl, sp.lm_coff.p, d_vals, sp.cinv.p);
 	if(sp.no)
 		hipLaunchKernelGGL((obs_kernel<DP, DL>), dim3((unsigned)((sp.no + 255) / 256)), dim3(256), 0, s,
-			sp.no, sp.obs_lm.p, sp.obs_off.p, sp.lm_rbase.p, d_vals, d_rhs, sp.cinv.p, sp.W.p, sp.Up.p, sp.xw.p);
+			sp.no, sp.obs_lm.p, sp.obs_off.p, sp.lm_rbase.p, d_vals, d_rhs, sp.cinv.p, sp.obs_wpos.p, sp.W.p, sp.Up.p, sp.xw.p);
 	phase_end(ctx, SPP_PHASE_SCHUR_INV);
 	phase_begin(ctx, SPP_PHASE_SCHUR_GEMM);
 	if(sp.n_items)
-		hipLaunchKernelGGL((s_accum_kernel<DP, DL>), dim3((unsigned)((sp.n_items + SACC_WAVES - 1) / SACC_WAVES)), dim3(SACC_WAVES * 64), 0, s,
-			sp.n_items, sp.item_blk.p, sp.item_beg.p, sp.item_slot.p, sp.sblk_i1.p, sp.sblk_i2.p, sp.sblk_aoff.p,
+		hipLaunchKernelGGL((s_accum_kernel<DP, DL>), dim3((unsigned)(8 * ((sp.xcd_max_items + SACC_WAVES - 1) / SACC_WAVES))), dim3(SACC_WAVES * 64), 0, s,
+			sp.n_items, sp.item_blk.p, sp.item_beg.p, sp.item_end.p, sp.xcd_beg.p, sp.item_slot.p, sp.sblk_i1.p, sp.sblk_i2.p, sp.sblk_aoff.p,
 			sp.pair_a.p, sp.pair_b.p, sp.W.p, sp.Up.p, d_vals, sp.add_A ? 1 : 0, S, ld, voff, sp.partial.p);
 	if(sp.n_multi)
 		hipLaunchKernelGGL((s_multi_kernel<DP>), dim3((unsigned)((sp.n_multi + 3) / 4)), dim3(256), 0, s,
@@ -361,7 +430,6 @@ static void schur_form_t(spp_ctx *ctx, const double *d_vals, const double *d_rhs
 template <int DP, int DL>
 static int schur_finish_t(spp_ctx *ctx, const double *d_vals, double *S, double *d_rhs)
 {
-	(void)d_vals;
 	SchurPlan &sp = ctx->schur;
 	hipStream_t s = ctx->stream;
 	const int64_t ld = sp.ld;
@@ -388,7 +456,7 @@ static int schur_finish_t(spp_ctx *ctx, const double *d_vals, double *S, double 
 	phase_begin(ctx, SPP_PHASE_BACKSUBST);
 	if(sp.nl)
 		hipLaunchKernelGGL((backsubst_kernel<DP, DL>), dim3((unsigned)((sp.nl + 255) / 256)), dim3(256), 0, s,
-			sp.nl, sp.lm_ptr.p, sp.obs_pose.p, sp.lm_rbase.p, sp.Up.p, sp.cinv.p, xcol, d_rhs);
+			sp.nl, sp.lm_ptr.p, sp.obs_pose.p, sp.lm_rbase.p, sp.obs_off.p, d_vals, sp.cinv.p, xcol, d_rhs);
 	if(sp.nc)
 		hipLaunchKernelGGL((scatter_dx_kernel<DP>), dim3((unsigned)((sp.nc * DP + 255) / 256)), dim3(256), 0, s,
 			sp.nc, sp.pose_rbase.p, xcol, d_rhs);

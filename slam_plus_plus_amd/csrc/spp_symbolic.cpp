@@ -23,7 +23,7 @@ void SchurPlan::release_all()
 {
 	lm_ptr.release(); lm_coff.release(); lm_rbase.release(); obs_pose.release(); obs_lm.release();
 	obs_off.release(); pose_rbase.release(); cam_ptr.release(); cam_obs.release(); item_blk.release();
-	item_beg.release(); item_slot.release(); sblk_i1.release(); sblk_i2.release(); sblk_aoff.release();
+	item_beg.release(); item_end.release(); obs_wpos.release(); xcd_beg.release(); item_slot.release(); sblk_i1.release(); sblk_i2.release(); sblk_aoff.release();
 	sblk_voff.release(); s_st = Structure(); sparse_S = false;
 	pair_a.release(); pair_b.release(); multi_blk.release(); multi_ptr.release(); cinv.release();
 	W.release(); Up.release(); xw.release(); partial.release(); S.release();
@@ -165,6 +165,12 @@ void build_schur_plan(spp_ctx *ctx, bool sparse_S)
 			cam_obs[fill[obs_pose[a]] ++] = (int32_t)a;
 	}
 
+	// camera-major position of every observation: W, Up, xw are stored in this order, so that the
+	// blocks one camera contributes are contiguous (the S accumulation gathers them per camera pair)
+	std::vector<int32_t> wpos(no);
+	for(int64_t q = 0; q < no; ++ q)
+		wpos[cam_obs[q]] = (int32_t)q;
+
 	// ---- S block pattern and pair lists. Key = (i1 <= i2). Two stable counting passes
 	// (by i1, then by i2... ) would reorder landmarks; instead count per key with a dense or
 	// hashed index and fill in landmark order, which keeps the reference's accumulation order
@@ -275,8 +281,14 @@ void build_schur_plan(spp_ctx *ctx, bool sparse_S)
 		sp.sblk_voff.upload(voff, s);
 	}
 
+	// the pair lists address W / Up, i.e. camera-major positions
+	for(int64_t q = 0; q < n_pairs; ++ q) {
+		pair_a[q] = wpos[pair_a[q]];
+		pair_b[q] = wpos[pair_b[q]];
+	}
+
 	// ---- work items: chunks of at most PAIR_CHUNK pairs
-	std::vector<int32_t> item_blk, item_beg, item_slot, multi_blk, multi_ptr;
+	std::vector<int32_t> item_blk, item_beg, item_end, item_slot, multi_blk, multi_ptr;
 	int32_t n_slots = 0;
 	for(int64_t b = 0; b < n_sblk; ++ b) {
 		const int64_t beg = sblk_beg[b], end = sblk_beg[b + 1];
@@ -288,13 +300,51 @@ void build_schur_plan(spp_ctx *ctx, bool sparse_S)
 		for(int64_t c = 0; c < nchunk; ++ c) {
 			item_blk.push_back((int32_t)b);
 			item_beg.push_back((int32_t)(beg + c * PAIR_CHUNK));
+			item_end.push_back((int32_t)std::min<int64_t>(end, beg + (c + 1) * PAIR_CHUNK));
 			item_slot.push_back(nchunk > 1 ? n_slots ++ : -1);
 		}
 	}
 	multi_ptr.push_back(n_slots);
-	item_beg.push_back((int32_t)n_pairs);
-	// the end of item i is min(item_beg[i+1], end of its block) == item_beg[i+1] by construction
+	// Item order = execution order. Blocks are visited tile by tile (SACC_TILE x SACC_TILE cameras):
+	// the W segments of the tile's row cameras and the U segments of its column cameras (~0.5 MB each
+	// on Venice) then stay in the L2 of the XCD that works through the tile (the kernel hands each XCD
+	// one contiguous range of items).
+	{
+		const int64_t TB = 4, ntile = (nc + TB - 1) / TB;
+		std::vector<int32_t> perm(item_blk.size());
+		for(size_t q = 0; q < perm.size(); ++ q)
+			perm[q] = (int32_t)q;
+		std::stable_sort(perm.begin(), perm.end(), [&](int32_t x, int32_t y) {
+			const int64_t kx = (sblk_i1[item_blk[x]] / TB) * ntile + sblk_i2[item_blk[x]] / TB;
+			const int64_t ky = (sblk_i1[item_blk[y]] / TB) * ntile + sblk_i2[item_blk[y]] / TB;
+			return kx < ky; });
+		std::vector<int32_t> t_blk(perm.size()), t_beg(perm.size()), t_end(perm.size()), t_slot(perm.size());
+		for(size_t q = 0; q < perm.size(); ++ q) {
+			t_blk[q] = item_blk[perm[q]];
+			t_beg[q] = item_beg[perm[q]];
+			t_end[q] = item_end[perm[q]];
+			t_slot[q] = item_slot[perm[q]];
+		}
+		item_blk.swap(t_blk); item_beg.swap(t_beg); item_end.swap(t_end); item_slot.swap(t_slot);
+	}
 	sp.n_items = (int64_t)item_blk.size();
+	// eight contiguous item ranges of equal WORK (one per XCD): a wave spends a fixed cost per item plus
+	// one gather round per 64 pairs; equal item counts would leave the last range ~45 % heavier
+	{
+		std::vector<int64_t> cost(sp.n_items + 1, 0);
+		for(int64_t q = 0; q < sp.n_items; ++ q)
+			cost[q + 1] = cost[q] + 2 + (item_end[q] - item_beg[q] + 63) / 64;
+		std::vector<int32_t> xb(9, 0);
+		for(int x = 1; x < 8; ++ x)
+			xb[x] = (int32_t)(std::lower_bound(cost.begin(), cost.end(), cost[sp.n_items] * x / 8) - cost.begin());
+		xb[8] = (int32_t)sp.n_items;
+		sp.xcd_max_items = 0;
+		for(int x = 0; x < 8; ++ x) {
+			xb[x + 1] = std::max(xb[x + 1], xb[x]);
+			sp.xcd_max_items = std::max(sp.xcd_max_items, xb[x + 1] - xb[x]);
+		}
+		sp.xcd_beg.upload(xb, s);
+	}
 	sp.n_multi = (int64_t)multi_blk.size();
 
 	// ---- rhs offsets
@@ -316,6 +366,8 @@ void build_schur_plan(spp_ctx *ctx, bool sparse_S)
 	sp.cam_obs.upload(cam_obs, s);
 	sp.item_blk.upload(item_blk, s);
 	sp.item_beg.upload(item_beg, s);
+	sp.item_end.upload(item_end, s);
+	sp.obs_wpos.upload(wpos, s);
 	sp.item_slot.upload(item_slot, s);
 	sp.sblk_i1.upload(sblk_i1, s);
 	sp.sblk_i2.upload(sblk_i2, s);
