@@ -120,7 +120,7 @@ def main():
 
     S = P = None
     schur = mode in (api.MODE_SCHUR, api.MODE_SCHUR_SPARSE)
-    if mode == api.MODE_SCHUR and world > 1:
+    if schur and world > 1:
         S = torch.empty(ctx.schur_buffer_size(), dtype=torch.float64, device="cuda")
         P = torch.empty(ctx.schur_packed_size(), dtype=torch.float64, device="cuda")  # upper trapezoid only
 
@@ -193,7 +193,7 @@ def main():
             "n_reduced": int(ctx.info("N_REDUCED")), "schur_pairs": int(ctx.info("SCHUR_PAIRS")),
             "parallelism": ("%s: landmark shards x%d + one RCCL all-reduce of the packed reduced camera system (%.0f MB)" % (
                 "weak (871 cameras, 530304 landmarks per GPU)" if weak else "strong (one Venice problem)", world,
-                8e-6 * ctx.schur_packed_size())) if (world > 1 and mode == api.MODE_SCHUR) else "single GPU"},
+                8e-6 * ctx.schur_packed_size())) if (world > 1 and schur) else "single GPU"},
         "gn_iters_per_s": gn_steps / dt_gn, "ms_per_gn_iter": 1e3 * dt_gn / gn_steps, "assemble_ms": assemble_ms,
         "phase_ms": {k: round(v, 4) for k, v in phase.items()}, "analyze_s": round(analyze_s, 3),
         "generate_s": round(gen_s, 2), "solution_norm": float(np.linalg.norm(x)),

@@ -52,7 +52,9 @@ extern "C" {
 #define SPP_MODE_SCHUR_SPARSE 3 /* guided Schur complement, the reduced camera system kept sparse (block-CSC) and
                                    solved by the supernodal path: CLinearSolver_Schur with a sparse inner solver,
                                    include/slam/LinearSolver_Schur.h:1844-1853. AUTO picks it beyond 16384 reduced
-                                   scalars (BASELINE config 5: 10k cameras). Single GPU (no landmark shards) for now */
+                                   scalars (BASELINE config 5: 10k cameras). Shards over landmarks like SPP_MODE_SCHUR: every
+                                   rank holds the union block structure of S, the all-reduced buffer is the block value
+                                   array followed by the reduced rhs */
 
 /* spp_create flags */
 #define SPP_FLAG_PROFILE  1   /* record hipEvents around the phases of each solve */

@@ -239,13 +239,13 @@ int spp_analyze(spp_ctx *ctx, int64_t nb, const int64_t *col_ptr, const int64_t 
 			int64_t n_red = 0;
 			for(int64_t j = 0; j < nb; ++ j)
 				n_red += (dim[j] == dp) ? dp : 0;
-			chosen = (n_red <= 16384 || ctx->shard_world > 1) ? SPP_MODE_SCHUR : SPP_MODE_SCHUR_SPARSE;
+			chosen = (n_red <= 16384) ? SPP_MODE_SCHUR : SPP_MODE_SCHUR_SPARSE;
 		}
 	}
 	SPP_REQUIRE(chosen == SPP_MODE_SCHUR || chosen == SPP_MODE_SPARSE || chosen == SPP_MODE_SCHUR_SPARSE, SPP_E_BADARG,
 		"unknown mode");
-	SPP_REQUIRE(chosen == SPP_MODE_SCHUR || ctx->shard_world == 1, SPP_E_UNSUPPORTED,
-		"only the Schur mode with a dense reduced system shards over landmarks (DESIGN.md, multi-GPU)");
+	SPP_REQUIRE(chosen != SPP_MODE_SPARSE || ctx->shard_world == 1, SPP_E_UNSUPPORTED,
+		"only the Schur modes shard (over landmarks); pose graphs run as replicas (DESIGN.md, multi-GPU)");
 	ctx->mode = -1;
 	if(chosen == SPP_MODE_SCHUR || chosen == SPP_MODE_SCHUR_SPARSE) {
 		const bool sparse_S = chosen == SPP_MODE_SCHUR_SPARSE;

@@ -137,6 +137,39 @@ void build_schur_plan(spp_ctx *ctx, bool sparse_S)
 	}
 	for(int64_t l = 0; l < nl; ++ l)
 		SPP_REQUIRE(lm_coff[l] >= 0, SPP_E_BADARG, "landmark without a diagonal block");
+	// Sharded + sparse reduced system: every rank must hold the SAME block structure of S (the union
+	// over all landmarks), or the all-reduce of the value arrays would add unrelated blocks. The pattern
+	// of the landmarks this rank does not own is collected here (pose lists per foreign landmark).
+	std::vector<std::vector<int32_t> > foreign_cols; // per pose i1: poses i2 > i1 co-observing a foreign landmark
+	if(sparse_S && ctx->shard_world > 1) {
+		std::vector<int64_t> lm_gidx(st.nb, -1);
+		int64_t g = 0;
+		for(int64_t j = 0; j < st.nb; ++ j)
+			if(st.dim[j] != dp)
+				lm_gidx[j] = g ++;
+		std::vector<std::vector<int32_t> > poses_of(g);
+		for(int64_t j = 0; j < st.nb; ++ j)
+			for(int64_t p = st.col_ptr[j]; p < st.col_ptr[j + 1]; ++ p) {
+				const int64_t i = st.row_idx[p];
+				const bool pi = st.dim[i] == dp, pj = st.dim[j] == dp;
+				if(pi && !pj && lm_of[j] < 0)
+					poses_of[lm_gidx[j]].push_back(pose_of[i]);
+				else if(!pi && pj && lm_of[i] < 0)
+					poses_of[lm_gidx[i]].push_back(pose_of[j]);
+			}
+		foreign_cols.resize(nc);
+		for(int64_t l = 0; l < g; ++ l) {
+			std::vector<int32_t> &ps = poses_of[l];
+			std::sort(ps.begin(), ps.end());
+			for(size_t a = 0; a < ps.size(); ++ a)
+				for(size_t b = a + 1; b < ps.size(); ++ b)
+					foreign_cols[ps[a]].push_back(ps[b]);
+		}
+		for(int64_t c = 0; c < nc; ++ c) {
+			std::sort(foreign_cols[c].begin(), foreign_cols[c].end());
+			foreign_cols[c].erase(std::unique(foreign_cols[c].begin(), foreign_cols[c].end()), foreign_cols[c].end());
+		}
+	}
 	std::sort(obs.begin(), obs.end(), [](const Obs &a, const Obs &b) {
 		return a.lm != b.lm ? a.lm < b.lm : a.pose < b.pose; });
 	const int64_t no = (int64_t)obs.size();
@@ -215,6 +248,7 @@ void build_schur_plan(spp_ctx *ctx, bool sparse_S)
 			a_by_row[ablk[q].i1].push_back(std::make_pair(ablk[q].i2, ablk[q].off));
 		std::vector<int64_t> col_cnt(nc + 1);
 		std::vector<int64_t> a_of_col(nc);
+		std::vector<char> foreign(nc, 0);
 		int64_t out = 0;
 		for(int64_t i1 = 0; i1 < nc; ++ i1) {
 			const int64_t b0 = row_cnt[i1], b1 = row_cnt[i1 + 1];
@@ -224,11 +258,14 @@ void build_schur_plan(spp_ctx *ctx, bool sparse_S)
 				++ col_cnt[obs_pose[tmp_b[q]] + 1];
 			for(size_t q = 0; q < a_by_row[i1].size(); ++ q)
 				a_of_col[a_by_row[i1][q].first] = a_by_row[i1][q].second;
+			if(!foreign_cols.empty())
+				for(size_t q = 0; q < foreign_cols[i1].size(); ++ q)
+					foreign[foreign_cols[i1][q]] = 1;
 			// blocks of this row, ascending i2
 			std::vector<int64_t> start(nc + 1, 0);
 			for(int64_t c = i1; c < nc; ++ c) {
 				start[c] = out;
-				if(col_cnt[c + 1] || a_of_col[c] >= 0) {
+				if(col_cnt[c + 1] || a_of_col[c] >= 0 || foreign[c]) {
 					sblk_i1.push_back((int32_t)i1);
 					sblk_i2.push_back((int32_t)c);
 					sblk_aoff.push_back(a_of_col[c]);
@@ -236,6 +273,9 @@ void build_schur_plan(spp_ctx *ctx, bool sparse_S)
 				}
 				out += col_cnt[c + 1];
 			}
+			if(!foreign_cols.empty())
+				for(size_t q = 0; q < foreign_cols[i1].size(); ++ q)
+					foreign[foreign_cols[i1][q]] = 0;
 			for(int64_t q = b0; q < b1; ++ q) { // stable: landmark order preserved
 				int64_t &f = start[obs_pose[tmp_b[q]]];
 				pair_a[f] = tmp_a[q];

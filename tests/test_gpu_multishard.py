@@ -11,18 +11,21 @@ from oracle import spp_oracle as orc
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name,world", [("ba_small", 2), ("ba_interleaved", 3), ("ba_medium", 2)])
-def test_sharded_schur_equals_unsharded(name, world):
+@pytest.mark.parametrize("name,world,mode", [("ba_small", 2, api.MODE_SCHUR), ("ba_interleaved", 3, api.MODE_SCHUR),
+                                             ("ba_medium", 2, api.MODE_SCHUR), ("ba_small", 2, api.MODE_SCHUR_SPARSE),
+                                             ("ba_banded", 3, api.MODE_SCHUR_SPARSE)])
+def test_sharded_schur_equals_unsharded(name, world, mode):
     prob = synth.make(name)
     lam, eta = orc.assemble(prob)
-    full = api.CLinearSolver_HIP(mode=api.MODE_SCHUR)
+    full = api.CLinearSolver_HIP(mode=mode)
     xfull = eta.copy()
     assert full.Solve_PosDef_Blocky(lam, xfull)
     ctxs, bufs = [], []
     for r in range(world):
         c = api.Context(0)
         c.set_shard(r, world)
-        c.analyze(lam, api.MODE_SCHUR)
+        c.analyze(lam, mode)
+        assert c.info("MODE") == mode
         dv = api.DeviceArray.from_host(c, lam.vals)
         dr = api.DeviceArray.from_host(c, eta)
         dS = api.DeviceArray(c, c.schur_buffer_size())
@@ -38,8 +41,12 @@ def test_sharded_schur_equals_unsharded(name, world):
         c.schur_pack(dS.ptr, dP.ptr)
         c.synchronize()
         packed.append(dP)
-    nblk = ctxs[0].info("S_LD") // 128
-    assert packed[0].n == 128 * 128 * nblk * (nblk + 1) // 2 <= bufs[0][2].n
+    if mode == api.MODE_SCHUR:
+        nblk = ctxs[0].info("S_LD") // 128
+        assert packed[0].n == 128 * 128 * nblk * (nblk + 1) // 2 <= bufs[0][2].n
+    else:  # sparse reduced system: block values | rhs, the same structure (union over all landmarks) on every rank
+        assert len({c.info("S_NNZB") for c in ctxs}) == 1 and ctxs[0].info("S_NNZB") == full.ctx.info("S_NNZB")
+        assert packed[0].n == bufs[0][2].n == 36 * ctxs[0].info("S_NNZB") + ctxs[0].info("N_REDUCED")
     psum = sum(p.download() for p in packed)  # the all-reduce
     for c, (dv, dr, dS), dP in zip(ctxs, bufs, packed):
         dP.upload(psum)

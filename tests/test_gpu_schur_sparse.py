@@ -78,3 +78,39 @@ def test_sparse_variant_not_posdef_returns_false_and_keeps_eta():
     x = eta.copy()
     assert solver.Solve_PosDef_Blocky(bad, x) is False
     assert np.array_equal(x, eta)
+
+
+def test_config5_full_size_properties():
+    """BASELINE.json config 5 at full size (10 000 cameras, 2 000 000 points, 10 000 000 observations),
+    entirely on the device: assembly, analysis (AUTO must keep the 60 000-unknown reduced system
+    sparse and pick nested dissection: a handful of tree levels, not thousands), solve.
+    Size-independent properties: tiny residual of the full system, bit-reproducibility, and the
+    damped solution shrinking when the damping grows."""
+    prob = synth.make("synthetic10k")
+    ctx = api.Context(0, api.FLAG_PROFILE)
+    st = ctx.assemble_analyze(prob.dim, prob.v0, prob.v1, prob.d0, prob.d1, prob.rd, prob.unary_vertex)
+    assert (st.nb, prob.v0.size) == (10000 + 2000000, 10000000)
+    arrs = [api.DeviceArray.from_host(ctx, a.ravel()) for a in (prob.J0, prob.J1, prob.Om, prob.r)]
+    dv, de, dr = api.DeviceArray(ctx, st.nvals), api.DeviceArray(ctx, st.n), api.DeviceArray(ctx, st.n)
+    ctx.assemble_device(*[a.ptr for a in arrs], prob.damping, dv.ptr, de.ptr)
+    ctx.analyze(st, api.MODE_AUTO)
+    assert ctx.info("MODE") == api.MODE_SCHUR_SPARSE and ctx.info("N_REDUCED") == 60000
+    assert ctx.info("N_LEVELS") < 64, "the elimination tree of the trajectory must not be a chain"
+    assert ctx.info("FACTOR_NNZ") < 0.01 * 60000 ** 2 / 2
+    xs = []
+    for _ in range(2):
+        dr.copy_from(de)
+        assert ctx.factor_solve_device(dv.ptr, dr.ptr) == 0
+        xs.append(dr.download())
+    assert np.array_equal(xs[0], xs[1]), "bit-reproducible"
+    lam = st.with_vals(dv.download())
+    eta = de.download()
+    res = np.linalg.norm(lam.matvec(xs[0]) - eta) / np.linalg.norm(eta)
+    assert res < 1e-12, res
+    ctx.assemble_device(*[a.ptr for a in arrs], 10 * prob.damping, dv.ptr, de.ptr)
+    dr.copy_from(de)
+    assert ctx.factor_solve_device(dv.ptr, dr.ptr) == 0
+    assert np.linalg.norm(dr.download()) < np.linalg.norm(xs[0])
+    for d in arrs + [dv, de, dr]:
+        d.free()
+    ctx.close()
