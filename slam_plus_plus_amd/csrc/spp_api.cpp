@@ -125,6 +125,8 @@ int spp_free_memory(spp_ctx *ctx)
 	ctx->dense.tinv.release();
 	ctx->dense.tinv_all.release();
 	ctx->dense.xtmp.release();
+	ctx->dense.flags.release();
+	ctx->dense.epoch = 0;
 	ctx->d_vals.release();
 	ctx->d_rhs.release();
 	ctx->mode = -1;
@@ -143,6 +145,8 @@ void spp_destroy(spp_ctx *ctx)
 		(void)hipEventDestroy(ctx->dense.ev[0]);
 		(void)hipEventDestroy(ctx->dense.ev[1]);
 	}
+	if(ctx->dense.h_chain_err)
+		(void)hipHostFree(ctx->dense.h_chain_err);
 	if(ctx->timer.created)
 		for(int i = 0; i < 2 * SPP_N_PHASES; ++ i)
 			(void)hipEventDestroy(ctx->timer.ev[i]);
@@ -180,6 +184,7 @@ int spp_synchronize(spp_ctx *ctx)
 		return SPP_E_BADARG;
 	SPP_TRY(ctx)
 	SPP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	dense_chain_check(ctx);
 	return SPP_OK;
 	SPP_CATCH(ctx)
 }
@@ -442,6 +447,7 @@ int spp_factor_solve_device(spp_ctx *ctx, const double *d_vals, double *d_rhs)
 	phase_end(ctx, SPP_PHASE_TOTAL);
 	phases_collect(ctx);
 	SPP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	dense_chain_check(ctx);
 	return ret;
 	SPP_CATCH(ctx)
 }

@@ -639,7 +639,98 @@ void trsv_back_kernel(const double *__restrict__ R, int64_t ld, int64_t k0, int 
 	}
 }
 
-__global__ void set_info_kernel(int *info) { info[0] = 0; }
+
+// Backward substitution as ONE launch: workgroup b owns block row b (128 rows), all workgroups are
+// resident (<= 1024 of them) and run the dependent chain x_last -> ... -> x_0 through global memory
+// instead of through 41 kernel launches. Workgroup b applies x_k to its rows for k = last .. b+1
+// as the x_k are published (flag[k] == epoch of this solve), then solves its diagonal block with the
+// stored inverse, publishes x_b and exits. Every wait depends only on workgroups with a larger index, which never
+// wait on smaller ones: no cycle. The spin is BOUNDED: on timeout the workgroup raises `err`, publishes
+// nothing and exits -- the ones below it time out the same way -- so the grid always drains.
+__global__ __launch_bounds__(256)
+void trsv_back_chain_kernel(const double *__restrict__ R, int64_t ld, int64_t n, int nblk,
+	const double *__restrict__ tinv_all, const double *__restrict__ y, double *xout, int *flags, int epoch, int *err)
+{
+	__shared__ double xs[NB];
+	__shared__ double part[2][NB];
+	__shared__ int ok;
+	const int b = blockIdx.x, tid = threadIdx.x, r = tid & (NB - 1), h = tid >> 7;
+	const int64_t r0 = (int64_t)NB * b;
+	// Everything that does not depend on an x_k is fetched ahead of the wait for it: the 64 entries of
+	// this thread's half row of the inverse diagonal block (kept for the whole kernel) and of the next
+	// R tile (refilled right after use). One workgroup per CU, one wave per SIMD: 512 VGPRs per lane.
+	double tv[64], rt[64];
+	{
+		const double *tinv = tinv_all + (size_t)b * NB * NB + r + (size_t)(64 * h) * NB;
+#pragma unroll
+		for(int c = 0; c < 64; ++ c)
+			tv[c] = tinv[(size_t)c * NB];
+	}
+	auto load_tile = [&](int k) {
+		const double *row = R + (r0 + r) + ((int64_t)NB * k + 64 * h) * ld;
+#pragma unroll
+		for(int c = 0; c < 64; ++ c)
+			rt[c] = row[(int64_t)c * ld];
+	};
+	if(nblk - 1 > b)
+		load_tile(nblk - 1);
+	double acc = (h == 0 && r0 + r < n) ? y[r0 + r] : 0.0; // each row is split over two threads (64 columns each)
+	for(int k = nblk - 1; k > b; -- k) {
+		if(tid == 0) {
+			int spins = 0;
+			// relaxed polling by ONE thread: an ACQUIRE load at agent scope invalidates the XCD's L2 on
+			// every poll (40 pollers thrash the caches of the workgroups that stream R), and 128 threads
+			// polling the data itself (x_k preset to a NaN pattern) was 2x slower than flag + fence;
+			// x_k is read with agent-scope atomic loads, which go to the coherent level on their own
+			while(__hip_atomic_load(&flags[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch && spins < (1 << 22)) {
+				__builtin_amdgcn_s_sleep(1);
+				++ spins;
+			}
+			ok = spins < (1 << 22);
+		}
+		__syncthreads();
+		if(!ok) {
+			if(tid == 0)
+				*err = 1;
+			return;
+		}
+		if(tid < NB)
+			xs[tid] = __hip_atomic_load(&xout[(int64_t)NB * k + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		__syncthreads();
+		const int64_t c0 = (int64_t)NB * k;
+		const int nvk = (int)((n - c0 < NB) ? (n - c0) : NB); // real columns of block k (its padding holds the rhs)
+		double s8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+		for(int c = 0; c < 64; ++ c)
+			s8[c & 7] += (64 * h + c < nvk) ? rt[c] * xs[64 * h + c] : 0.0;
+		acc -= ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+		if(k - 1 > b)
+			load_tile(k - 1); // in flight while this workgroup waits for x_{k-1}
+		__syncthreads(); // xs is overwritten by the next block
+	}
+	part[h][r] = acc;
+	__syncthreads();
+	if(tid < NB)
+		xs[tid] = part[0][tid] + part[1][tid]; // y_b with everything to its right eliminated
+	__syncthreads();
+	{
+		const int nv = (int)((n - r0 < NB) ? (n - r0) : NB);
+		double s8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+		for(int c = 0; c < 64; ++ c)
+			s8[c & 7] += (64 * h + c < nv) ? tv[c] * xs[64 * h + c] : 0.0;
+		part[h][r] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+	}
+	__syncthreads();
+	if(tid < NB)
+		__hip_atomic_store(&xout[r0 + tid], part[0][tid] + part[1][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	__threadfence();
+	__syncthreads();
+	if(tid == 0)
+		__hip_atomic_store(&flags[b], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void set_info_kernel(int *info) { info[0] = 0; info[1] = 0; }
 
 // padding diagonal = 1 (rows/cols >= n); the rows >= n of the rhs column (column n) are cleared so
 // that the solves never touch non-finite garbage
@@ -830,6 +921,14 @@ void dense_info_reset(spp_ctx *ctx)
 	hipLaunchKernelGGL(set_info_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->dense.info.p);
 }
 
+void dense_chain_check(spp_ctx *ctx)
+{
+	if(ctx->dense.h_chain_err && *ctx->dense.h_chain_err) {
+		*ctx->dense.h_chain_err = 0;
+		throw Error(SPP_E_HIP, "backward substitution: a workgroup of the chain kernel timed out waiting for its predecessor");
+	}
+}
+
 int dense_info_fetch(spp_ctx *ctx)
 {
 	int h_info = 0;
@@ -852,6 +951,33 @@ void dense_potrs_upper(spp_ctx *ctx, const double *d_R, int64_t n, int64_t ld, d
 {
 	const int64_t nblk = (n + NB - 1) / NB;
 	hipStream_t s = ctx->stream;
+	static int chain = -1;
+	if(chain < 0) {
+		const char *e = getenv("SPP_TRSV_CHAIN");
+		chain = e ? atoi(e) : 1;
+	}
+	if(chain && nblk > 1 && nblk <= 1024) {
+		// one launch, the dependent chain runs through device flags (info[1] = timeout flag)
+		DenseWork &dw = ctx->dense;
+		if(dw.flags.cap < (size_t)nblk) {
+			dw.flags.reserve((size_t)nblk);
+			SPP_HIP_CHECK(hipMemsetAsync(dw.flags.p, 0, (size_t)nblk * sizeof(int), s));
+			dw.epoch = 0;
+		}
+		if(!dw.h_chain_err) {
+			SPP_HIP_CHECK(hipHostMalloc((void**)&dw.h_chain_err, sizeof(int), hipHostMallocDefault));
+			*dw.h_chain_err = 0;
+		}
+		++ dw.epoch;
+		hipLaunchKernelGGL(trsv_back_chain_kernel, dim3((unsigned)nblk), dim3(256), 0, s, d_R, ld, n, (int)nblk,
+			dw.tinv_all.p, d_b, dw.xtmp.p, dw.flags.p, dw.epoch, dw.info.p + 1);
+		SPP_HIP_CHECK(hipGetLastError());
+		SPP_HIP_CHECK(hipMemcpyAsync(d_b, dw.xtmp.p, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+		// the timeout flag travels to pinned host memory; dense_chain_check() looks at it after the
+		// next synchronization of the stream (no extra round trip)
+		SPP_HIP_CHECK(hipMemcpyAsync(dw.h_chain_err, dw.info.p + 1, sizeof(int), hipMemcpyDeviceToHost, s));
+		return;
+	}
 	for(int64_t k = nblk; k > 0;) {
 		-- k;
 		const int64_t k0 = k * NB;

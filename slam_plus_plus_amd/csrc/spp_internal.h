@@ -128,6 +128,9 @@ struct DenseWork {
 	DevBuf<int> info;              // device flag: 0 ok, j+1 = pivot j non-positive
 	DevBuf<double> tinv_all;       // inverses of all diagonal blocks (nblk x NB x NB) kept for the solves
 	DevBuf<double> xtmp;           // solution of the backward substitution before it replaces y
+	DevBuf<int> flags;             // per block row: epoch of the solve that last published x_b (chain kernel)
+	int epoch = 0;
+	int *h_chain_err = nullptr;    // pinned: timeout flag of the chain kernel, valid after a stream sync
 	hipStream_t aux = nullptr;     // lookahead stream: potrf_diag + trsm of the next panel
 	hipEvent_t ev[2] = {nullptr, nullptr};
 };
@@ -205,6 +208,7 @@ void dense_factor_steps(spp_ctx *ctx, double *d_A, int64_t ld, int64_t n, int64_
 void dense_info_reset(spp_ctx *ctx);
 void dense_reserve(spp_ctx *ctx, int64_t nblk); // workspaces for nblk diagonal blocks (call at analyze time)
 int dense_info_fetch(spp_ctx *ctx);
+void dense_chain_check(spp_ctx *ctx); // call after the stream was synchronized
 void dense_set_padding(spp_ctx *ctx, double *d_A, int64_t ld, int64_t n);
 bool dense_gemm_tn_sub(spp_ctx *ctx, int64_t m, int64_t n, int64_t k, const double *A, int64_t lda,
 	const double *B, int64_t ldb, double *C, int64_t ldc, bool upper_only);
