@@ -139,7 +139,9 @@ def main():
         if code != 0:
             raise SystemExit("factorization failed (not positive definite): code %d" % code)
 
-    # ---- timed region: exactly K Lambda-solves
+    # ---- timed region: exactly K Lambda-solves, profiling instrumentation OFF (the hipEvents around
+    # the phases and around every trailing-update launch cost a barrier packet each)
+    ctx.set_profiling(False)
     for _ in range(args.warmup):
         solve()
     ctx.synchronize()
@@ -154,8 +156,14 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    # ---- separate profiled pass: phase breakdown and the hipEvent-timed dominant kernel (last solve)
+    ctx.set_profiling(True)
+    for _ in range(3):
+        solve()
+    ctx.synchronize()
     phase = ctx.phase_ms()
     dom_ms, dom_n, dom_flops = ctx.dominant_kernel()
+    ctx.set_profiling(False)
 
     # ---- second loop: full GN iteration of device work (assembly + eta + solve)
     gn_steps = max(3, args.steps // 2)
@@ -171,6 +179,7 @@ def main():
         tt = torch.tensor([dt_gn], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt_gn = float(tt.item())
+    ctx.set_profiling(True)
     assemble()
     ctx.synchronize()
     assemble_ms = ctx.phase_ms()["assemble"]
@@ -195,7 +204,8 @@ def main():
                 "weak (871 cameras, 530304 landmarks per GPU)" if weak else "strong (one Venice problem)", world,
                 8e-6 * ctx.schur_packed_size())) if (world > 1 and schur) else "single GPU"},
         "gn_iters_per_s": gn_steps / dt_gn, "ms_per_gn_iter": 1e3 * dt_gn / gn_steps, "assemble_ms": assemble_ms,
-        "phase_ms": {k: round(v, 4) for k, v in phase.items()}, "analyze_s": round(analyze_s, 3),
+        "phase_ms": {k: round(v, 4) for k, v in phase.items()},
+        "phase_ms_note": "separate pass with SPP_FLAG_PROFILE on (hipEvents per phase and per trailing-update launch); ms_per_step is timed with profiling off", "analyze_s": round(analyze_s, 3),
         "generate_s": round(gen_s, 2), "solution_norm": float(np.linalg.norm(x)),
     }
     # ---- roofline of the dominant kernel (hipEvents on the ctx stream, last timed solve)

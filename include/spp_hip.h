@@ -169,6 +169,11 @@ int spp_memcpy_d2h(spp_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
 /* asynchronous on the ctx stream */
 int spp_memcpy_d2d(spp_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);
 
+/* switch SPP_FLAG_PROFILE on / off for the following solves (the hipEvents around phases and around the
+ * dominant kernel cost microseconds per solve; a benchmark times with profiling off and reads the
+ * breakdown from a separate profiled pass) */
+int spp_set_profiling(spp_ctx *ctx, int on);
+
 /* ---- profiling (SPP_FLAG_PROFILE) ------------------------------------------------------------------
  * phase names follow the reference's __SCHUR_PROFILING / Dump() vocabulary
  * (LinearSolver_Schur.h:1889-1912, NonlinearSolver_Lambda.h:250-276). */

@@ -15,6 +15,10 @@
  *
  * usage: dropin_driver [n_poses] [n_loop_closures]     ->  "poses .. max_abs_diff <d> .."
  *        dropin_driver ba [n_cams] [n_points]           ->  "ba cams .. max_abs_diff <d> .."
+ *        dropin_driver dump n_poses n_loop_closures file -> golden vector of the reference's Gauss-Newton
+ *            loop alone (reference linear solver, no GPU): edges, the initial vertex states the reference
+ *            derives from them, and the states after Optimize(5, 0.01) (slam_app's defaults,
+ *            src/slam_app/Main.cpp:706-707). tools/make_golden_gn.py turns it into tests/golden/*.npz.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -81,7 +85,8 @@ static void Generate(size_t n_poses, size_t n_loops, std::vector<TEdge> &r_edges
 }
 
 template <class CLinearSolverType>
-static bool Run(const std::vector<TEdge> &r_edges, std::vector<double> &r_state, size_t n_max_iter)
+static bool Run(const std::vector<TEdge> &r_edges, std::vector<double> &r_state, size_t n_max_iter,
+	double f_threshold = 1e-6, std::vector<double> *p_initial_state = 0)
 {
 	CSystemType system;
 	CNonlinearSolver_Lambda<CSystemType, CLinearSolverType> solver(system);
@@ -89,7 +94,15 @@ static bool Run(const std::vector<TEdge> &r_edges, std::vector<double> &r_state,
 	information << 1111.11, 0, 0, 0, 1111.11, 0, 0, 0, 10000;
 	for(size_t i = 0; i < r_edges.size(); ++ i)
 		system.r_Add_Edge(CEdgePose2D(r_edges[i].a, r_edges[i].b, r_edges[i].z, information, system));
-	solver.Optimize(n_max_iter, 1e-6);
+	if(p_initial_state) {
+		p_initial_state->clear();
+		for(size_t i = 0, n = system.r_Vertex_Pool().n_Size(); i < n; ++ i) {
+			Eigen::VectorXd v = system.r_Vertex_Pool()[i].v_State();
+			for(int j = 0; j < v.rows(); ++ j)
+				p_initial_state->push_back(v(j));
+		}
+	}
+	solver.Optimize(n_max_iter, f_threshold);
 	r_state.clear();
 	for(size_t i = 0, n = system.r_Vertex_Pool().n_Size(); i < n; ++ i) {
 		Eigen::VectorXd v = system.r_Vertex_Pool()[i].v_State();
@@ -206,6 +219,26 @@ int main(int n_arg_num, const char **p_arg_list)
 			return 2;
 		}
 		return Compare("ba cams/points", n_cams, n_points, ref_state, hip_state, 1e-7);
+	}
+	if(n_arg_num > 4 && !strcmp(p_arg_list[1], "dump")) {
+		size_t n_poses = atol(p_arg_list[2]), n_loops = atol(p_arg_list[3]);
+		std::vector<TEdge> edges;
+		Generate(n_poses, n_loops, edges);
+		std::vector<double> init, fin;
+		Run<CLinearSolver_UberBlock<CSystemType::_TyHessianMatrixBlockList> >(edges, fin, 5, 0.01, &init);
+		FILE *p_fw = fopen(p_arg_list[4], "w");
+		if(!p_fw)
+			return 2;
+		fprintf(p_fw, "SE2GN %lu %lu 5 0.01\n", (unsigned long)(init.size() / 3), (unsigned long)edges.size());
+		for(size_t i = 0; i < edges.size(); ++ i)
+			fprintf(p_fw, "E %lu %lu %.17g %.17g %.17g\n", (unsigned long)edges[i].a, (unsigned long)edges[i].b,
+				edges[i].z(0), edges[i].z(1), edges[i].z(2));
+		for(size_t i = 0; i + 2 < init.size(); i += 3)
+			fprintf(p_fw, "I %.17g %.17g %.17g\n", init[i], init[i + 1], init[i + 2]);
+		for(size_t i = 0; i + 2 < fin.size(); i += 3)
+			fprintf(p_fw, "F %.17g %.17g %.17g\n", fin[i], fin[i + 1], fin[i + 2]);
+		fclose(p_fw);
+		return 0;
 	}
 	size_t n_poses = (n_arg_num > 1)? atol(p_arg_list[1]) : 400;
 	size_t n_loops = (n_arg_num > 2)? atol(p_arg_list[2]) : 200;

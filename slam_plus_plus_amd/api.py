@@ -32,7 +32,7 @@ EXPORTS = [
     "spp_schur_packed_size", "spp_schur_pack", "spp_schur_unpack",
     "spp_assemble_analyze", "spp_assemble_get_structure", "spp_assemble_device", "spp_device_malloc",
     "spp_device_free", "spp_memcpy_h2d", "spp_memcpy_d2h", "spp_memcpy_d2d", "spp_get_phase_ms", "spp_get_dominant_kernel",
-    "spp_microbench_copy", "spp_microbench_mfma_f64", "spp_microbench_ctile", "spp_block_ordering", "spp_dense_potrf_upper", "spp_dense_posv",
+    "spp_microbench_copy", "spp_microbench_mfma_f64", "spp_microbench_ctile", "spp_block_ordering", "spp_set_profiling", "spp_dense_potrf_upper", "spp_dense_posv",
     "spp_dense_gemm_tn_sub", "spp_version",
 ]
 
@@ -88,6 +88,7 @@ def load_library():
         "spp_microbench_mfma_f64": (cint, [vp, cint, _c_f64p]),
         "spp_microbench_ctile": (cint, [vp, cint, cint, _c_f64p]),
         "spp_block_ordering": (cint, [ctypes.c_int64, vp, vp, cint, vp]),
+        "spp_set_profiling": (cint, [vp, cint]),
         "spp_dense_potrf_upper": (cint, [vp, vp, i64, i64]),
         "spp_dense_posv": (cint, [vp, vp, i64, i64, vp]),
         "spp_dense_gemm_tn_sub": (cint, [vp, i64, i64, i64, vp, i64, vp, i64, vp, i64]),
@@ -208,6 +209,9 @@ class Context:
         out = np.empty(nb, dtype=np.int64)
         self._check(self.lib.spp_get_ordering(self.h, _ptr(out)))
         return out
+
+    def set_profiling(self, on):
+        return self._check(self.lib.spp_set_profiling(self.h, 1 if on else 0))
 
     def set_stream(self, stream_handle):
         return self._check(self.lib.spp_set_stream(self.h, ctypes.c_void_p(stream_handle)))

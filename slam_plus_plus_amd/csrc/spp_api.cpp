@@ -189,6 +189,14 @@ int spp_synchronize(spp_ctx *ctx)
 	SPP_CATCH(ctx)
 }
 
+int spp_set_profiling(spp_ctx *ctx, int on)
+{
+	if(!ctx)
+		return SPP_E_BADARG;
+	ctx->flags = on ? (ctx->flags | SPP_FLAG_PROFILE) : (ctx->flags & ~SPP_FLAG_PROFILE);
+	return SPP_OK;
+}
+
 int spp_set_shard(spp_ctx *ctx, int rank, int world_size)
 {
 	if(!ctx || world_size < 1 || rank < 0 || rank >= world_size)

@@ -167,6 +167,11 @@ static const int MID_FRONT_MAX = 384; // padded height up to which ONE workgroup
 void sparse_analyze(spp_ctx *ctx, const Structure &st)
 {
 	const int64_t nb = st.nb;
+	// fronts above this padded height go to the dense MFMA kernels (one after the other, many workgroups
+	// each) instead of the one-workgroup in-place kernel; SPP_MID_FRONT_MAX tunes the split (<= 384)
+	int mid_front_max = MID_FRONT_MAX;
+	if(const char *e = getenv("SPP_MID_FRONT_MAX"))
+		mid_front_max = std::max(128, std::min(MID_FRONT_MAX, atoi(e)));
 	sparse_release(ctx);
 	SparsePlan *sp = new SparsePlan;
 	ctx->sparse = sp;
@@ -396,7 +401,7 @@ void sparse_analyze(spp_ctx *ctx, const Structure &st)
 		// (hp16 <= 32 / 64 / 128); larger fronts live padded in HBM: pivot block rounded up to 128
 		// with identity so that the dense 128-block kernels apply unchanged
 		const int32_t w16 = (w + 15) & ~15, hp16 = (w16 + (h - w) + 15) & ~15;
-		int32_t cls = hp16 <= 32 ? 0 : (hp16 <= 64 ? 1 : (hp16 <= 128 ? 2 : (hp16 <= MID_FRONT_MAX ? 3 : 4)));
+		int32_t cls = hp16 <= 32 ? 0 : (hp16 <= 64 ? 1 : (hp16 <= 128 ? 2 : (hp16 <= mid_front_max ? 3 : 4)));
 		front_cls[s] = cls;
 		front_pad[s] = (cls == 4) ? (((w + 127) & ~127) - w) : (cls == 3 ? w16 - w : 0);
 		// class 3 works on whole 16 x 16 tiles in place: its HBM image is rounded up to tiles

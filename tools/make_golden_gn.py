@@ -1,0 +1,34 @@
+"""Golden vector of the reference's Gauss-Newton loop (CNonlinearSolver_Lambda::Optimize(5, 0.01) with the
+reference's own CLinearSolver_UberBlock, CPU only) on a generated 2D pose graph:
+    make -C oracle dropin && python tools/make_golden_gn.py 400 200
+runs oracle/_ref/dropin_driver dump ... (reference code compiled from /root/reference) and stores
+edges, information, the initial states the reference derives from the edges, and the optimized states
+in tests/golden/se2_gn_<n>.npz."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+n_poses = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+n_loops = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+with tempfile.TemporaryDirectory() as td:
+    path = os.path.join(td, "gn.txt")
+    subprocess.run([os.path.join(ROOT, "oracle", "_ref", "dropin_driver"), "dump", str(n_poses), str(n_loops), path], check=True)
+    edges, init, final = [], [], []
+    for ln in open(path):
+        t = ln.split()
+        if t[0] == "E":
+            edges.append([float(x) for x in t[1:6]])
+        elif t[0] == "I":
+            init.append([float(x) for x in t[1:4]])
+        elif t[0] == "F":
+            final.append([float(x) for x in t[1:4]])
+edges, init, final = np.array(edges), np.array(init), np.array(final)
+info = np.tile(np.diag([1111.11, 1111.11, 10000.0]), (edges.shape[0], 1, 1))
+out = os.path.join(ROOT, "tests", "golden", "se2_gn_%d.npz" % n_poses)
+np.savez_compressed(out, edges=edges, info_diag=np.array([1111.11, 1111.11, 10000.0]), init=init, final=final,
+                    max_iter=5, threshold=0.01)
+print(out, edges.shape, init.shape, "moved by", np.abs(final - init).max())
