@@ -611,6 +611,10 @@ void front_lds_kernel(const int32_t *__restrict__ list, const int64_t *__restric
 	double *Gd = Dv + 16 * PT;          // (unused by the fronts, written by diag_tile_factor)
 	double *dinv = Gd + 16 * PT;        // HP
 	int *fail = (int*)(dinv + HP);
+	// GMEM: LDS copy of the current 16-row panel (all columns of the front), stride PLS per column: the
+	// trailing update takes its operands from here instead of re-reading them from HBM tile by tile
+	constexpr int PLS = 17;
+	double *Pl = dinv + HP + 2;
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int l15 = lane & 15, l4 = lane >> 4;
 	if(GMEM) {
@@ -668,22 +672,104 @@ void front_lds_kernel(const int32_t *__restrict__ list, const int64_t *__restric
 #pragma unroll
 			for(int r = 0; r < 4; ++ r)
 				Y[(l4 + 4 * r) + l15 * TSF] = x[r];
+			if(GMEM) {
+#pragma unroll
+				for(int r = 0; r < 4; ++ r)
+					Pl[(l4 + 4 * r) + (K * 16 + l15) * PLS] = x[r];
+			}
 		}
 		__syncthreads();
-		{ // C: trailing update, tiles (I <= K) of the remaining (nt - J - 1) tile rows
+		if(GMEM) {
+			// C for the HBM image: operands from the LDS panel copy, MFMA operands swapped so that a lane
+			// group covers 16 consecutive ROWS of the target tile (128-byte segments of 4 columns per access
+			// instead of 32 bytes out of 16 different cache lines), two tiles per wave in flight
 			const int nI = nt - 1 - J, nR = nI * (nI + 1) / 2;
-			for(int q = wave; q < nR; q += NW) {
+			auto decode = [&](int q, int &I, int &K) {
 				int a = 0, rem = q;
 				while(rem >= nI - a) {
 					rem -= nI - a;
 					++ a;
 				}
-				const int I = J + 1 + a, K = I + rem;
-				const v4f64 d = tile_atb(T + j0 + (I * 16) * TSF, 1, TSF, T + j0 + (K * 16) * TSF, 1, TSF, lane);
-				double *D = T + (I * 16) + (K * 16) * TSF;
+				I = J + 1 + a;
+				K = I + rem;
+			};
+			for(int q = wave; q < nR; q += 2 * NW) {
+				const int q1 = q + NW;
+				int I0, K0, I1 = 0, K1 = 0;
+				decode(q, I0, K0);
+				const bool have1 = q1 < nR;
+				if(have1)
+					decode(q1, I1, K1);
+				// lane (l15, l4 + 4 r) <-> D[I 16 + l15][K 16 + l4 + 4 r]
+				double *D0 = T + (I0 * 16 + l15) + (int64_t)(K0 * 16 + l4) * TSF;
+				if(have1) {
+					double *D1 = T + (I1 * 16 + l15) + (int64_t)(K1 * 16 + l4) * TSF;
+					double o0[4], o1[4];
 #pragma unroll
-				for(int r = 0; r < 4; ++ r)
-					D[(l4 + 4 * r) + l15 * TSF] -= d[r];
+					for(int r = 0; r < 4; ++ r) {
+						o0[r] = D0[(int64_t)(4 * r) * TSF];
+						o1[r] = D1[(int64_t)(4 * r) * TSF];
+					}
+					v4f64 d0, d1;
+					tile_atb2_rt(PLS, Pl + (K0 * 16) * PLS, Pl + (I0 * 16) * PLS, 1, PLS,
+						Pl + (K1 * 16) * PLS, Pl + (I1 * 16) * PLS, 1, PLS, lane, d0, d1);
+#pragma unroll
+					for(int r = 0; r < 4; ++ r) {
+						D0[(int64_t)(4 * r) * TSF] = o0[r] - d0[r];
+						D1[(int64_t)(4 * r) * TSF] = o1[r] - d1[r];
+					}
+				} else {
+					const v4f64 d = tile_atb(Pl + (K0 * 16) * PLS, 1, PLS, Pl + (I0 * 16) * PLS, 1, PLS, lane);
+#pragma unroll
+					for(int r = 0; r < 4; ++ r)
+						D0[(int64_t)(4 * r) * TSF] -= d[r];
+				}
+			}
+		} else
+		{ // C: trailing update, tiles (I <= K) of the remaining (nt - J - 1) tile rows. A wave works on two
+		  // tiles at a time and fetches the old target tiles together with the operands: every access is
+		  // a full memory round trip when the image lives in HBM, and one tile at a time left the wave
+		  // waiting on three dependent ones per tile.
+			const int nI = nt - 1 - J, nR = nI * (nI + 1) / 2;
+			auto decode = [&](int q, int &I, int &K) {
+				int a = 0, rem = q;
+				while(rem >= nI - a) {
+					rem -= nI - a;
+					++ a;
+				}
+				I = J + 1 + a;
+				K = I + rem;
+			};
+			for(int q = wave; q < nR; q += 2 * NW) {
+				const int q1 = q + NW;
+				int I0, K0, I1 = 0, K1 = 0;
+				decode(q, I0, K0);
+				const bool have1 = q1 < nR;
+				if(have1)
+					decode(q1, I1, K1);
+				double *D0 = T + (I0 * 16) + (K0 * 16) * TSF;
+				if(have1) {
+					double *D1 = T + (I1 * 16) + (K1 * 16) * TSF;
+					double o0[4], o1[4];
+#pragma unroll
+					for(int r = 0; r < 4; ++ r) {
+						o0[r] = D0[(l4 + 4 * r) + l15 * TSF];
+						o1[r] = D1[(l4 + 4 * r) + l15 * TSF];
+					}
+					v4f64 d0, d1;
+					tile_atb2_rt(TSF, T + j0 + (I0 * 16) * TSF, T + j0 + (K0 * 16) * TSF, 1, TSF,
+						T + j0 + (I1 * 16) * TSF, T + j0 + (K1 * 16) * TSF, 1, TSF, lane, d0, d1);
+#pragma unroll
+					for(int r = 0; r < 4; ++ r) {
+						D0[(l4 + 4 * r) + l15 * TSF] = o0[r] - d0[r];
+						D1[(l4 + 4 * r) + l15 * TSF] = o1[r] - d1[r];
+					}
+				} else {
+					const v4f64 d = tile_atb(T + j0 + (I0 * 16) * TSF, 1, TSF, T + j0 + (K0 * 16) * TSF, 1, TSF, lane);
+#pragma unroll
+					for(int r = 0; r < 4; ++ r)
+						D0[(l4 + 4 * r) + l15 * TSF] -= d[r];
+				}
 			}
 		}
 		__syncthreads();
@@ -915,7 +1001,7 @@ static void launch_front_lds(spp_ctx *ctx, SparsePlan *sp, int32_t b, int32_t e,
 {
 	if(e <= b)
 		return;
-	const size_t lds = ((GMEM ? 0 : (size_t)HP * (HP + 1)) + 2 * 16 * PT + HP + 8) * sizeof(double);
+	const size_t lds = ((GMEM ? (size_t)17 * HP : (size_t)HP * (HP + 1)) + 2 * 16 * PT + HP + 8) * sizeof(double);
 	static bool attr = false;
 	if(!attr) {
 		SPP_HIP_CHECK(hipFuncSetAttribute((const void*)front_lds_kernel<HP, NTH, GMEM>,
