@@ -162,6 +162,21 @@ int spp_assemble_device(spp_ctx *ctx, const double *d_J0, const double *d_J1,
 	const double *d_Omega, const double *d_r, double damping, double *d_vals_out, double *d_eta_out);
 
 /* ---- device memory helpers for hosts without a HIP runtime of their own ---------------------------- */
+/* ---- on-device geometry of 2D pose graphs (CEdgePose2D) --------------------------
+ * spp_se2_linearize_device: per edge (pose v0 -> pose v1, measurement z = dx dy dtheta in the frame of
+ * v0) the Jacobians of the expectation and the error r = z - h(x), exactly the quantities of
+ * C2DJacobians::Absolute_to_Relative (include/slam/2DSolverBase.h:373-418) and CEdgePose2D (angle error
+ * wrapped by f_ClampAngularError_2Pi, :90-94), written in the layout spp_assemble_device reads
+ * (J0, J1: ne x 3x3 column-major, r: ne x 3). All pointers are device pointers; v0 / v1 are int32.
+ * spp_se2_update_device: ||dx||^2 -> *h_dx_norm2 (deterministic two-stage sum) and, if `apply`,
+ * x <- x (+) dx with the angle clamped (CVertexPose2D::Operator_Plus, include/slam/SE2_Types.h:70-74).
+ * It synchronizes the stream: the stopping test of the Gauss-Newton loop needs the norm on the host
+ * (NonlinearSolver_Lambda.h:638-650). */
+int spp_se2_linearize_device(spp_ctx *ctx, int64_t n_edges, const int32_t *d_v0, const int32_t *d_v1,
+	const double *d_poses, const double *d_measurements, double *d_J0, double *d_J1, double *d_r);
+int spp_se2_update_device(spp_ctx *ctx, int64_t n_vertices, double *d_poses, const double *d_dx, int apply,
+	double *h_dx_norm2);
+
 int spp_device_malloc(spp_ctx *ctx, size_t bytes, void **d_ptr);
 int spp_device_free(spp_ctx *ctx, void *d_ptr);
 int spp_memcpy_h2d(spp_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);

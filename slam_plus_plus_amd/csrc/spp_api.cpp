@@ -125,6 +125,7 @@ int spp_free_memory(spp_ctx *ctx)
 	ctx->dense.tinv.release();
 	ctx->dense.tinv_all.release();
 	ctx->dense.xtmp.release();
+	ctx->geom_partial.release();
 	ctx->dense.flags.release();
 	ctx->dense.epoch = 0;
 	ctx->d_vals.release();
@@ -513,6 +514,32 @@ int spp_assemble_device(spp_ctx *ctx, const double *d_J0, const double *d_J1, co
 	assemble_run(ctx, d_J0, d_J1, d_Omega, d_r, damping, d_vals_out, d_eta_out);
 	phase_end(ctx, SPP_PHASE_ASSEMBLE);
 	phases_collect(ctx);
+	return SPP_OK;
+	SPP_CATCH(ctx)
+}
+
+int spp_se2_linearize_device(spp_ctx *ctx, int64_t n_edges, const int32_t *d_v0, const int32_t *d_v1,
+	const double *d_poses, const double *d_measurements, double *d_J0, double *d_J1, double *d_r)
+{
+	if(!ctx || n_edges < 0 || !d_v0 || !d_v1 || !d_poses || !d_measurements || !d_J0 || !d_J1 || !d_r)
+		return SPP_E_BADARG;
+	SPP_TRY(ctx)
+	SPP_HIP_CHECK(hipSetDevice(ctx->device));
+	se2_linearize(ctx, n_edges, d_v0, d_v1, d_poses, d_measurements, d_J0, d_J1, d_r);
+	return SPP_OK;
+	SPP_CATCH(ctx)
+}
+
+int spp_se2_update_device(spp_ctx *ctx, int64_t n_vertices, double *d_poses, const double *d_dx, int apply,
+	double *h_dx_norm2)
+{
+	if(!ctx || n_vertices < 0 || !d_poses || !d_dx)
+		return SPP_E_BADARG;
+	SPP_TRY(ctx)
+	SPP_HIP_CHECK(hipSetDevice(ctx->device));
+	const double n2 = se2_update(ctx, n_vertices, d_poses, d_dx, apply != 0);
+	if(h_dx_norm2)
+		*h_dx_norm2 = n2;
 	return SPP_OK;
 	SPP_CATCH(ctx)
 }

@@ -169,6 +169,7 @@ struct spp_ctx {
 	spp::AssemblePlan *assemble = nullptr;
 	// staging buffers for the host-pointer entry points
 	spp::DevBuf<double> d_vals, d_rhs;
+	spp::DevBuf<double> geom_partial; // partial sums of ||dx||^2 (spp_geometry.hip)
 	// profiling
 	spp::PhaseTimer timer;
 	double phase_ms[SPP_N_PHASES] = {0};
@@ -180,6 +181,11 @@ struct spp_ctx {
 };
 
 namespace spp {
+
+// ---- spp_geometry.hip ----
+void se2_linearize(spp_ctx *ctx, int64_t ne, const int32_t *d_v0, const int32_t *d_v1, const double *d_poses,
+	const double *d_meas, double *d_J0, double *d_J1, double *d_r);
+double se2_update(spp_ctx *ctx, int64_t nv, double *d_poses, const double *d_dx, bool apply);
 
 // ---- spp_symbolic.cpp ----
 void min_degree_order(int64_t nb, const int64_t *col_ptr, const int64_t *row_idx, std::vector<int64_t> &order);

@@ -62,13 +62,60 @@ class _DevicePath:
         self.ctx.close()
 
 
+class _ResidentPath:
+    """the whole Gauss-Newton iteration in HBM: linearization (spp_se2_linearize_device), assembly, solve,
+    ||dx|| and the vertex update (spp_se2_update_device). Host traffic per iteration: 8 bytes (the norm)."""
+
+    def __init__(self, device=0):
+        self.ctx = api.Context(device)
+
+    def begin(self, system):
+        ctx = self.ctx
+        prob = se2_linearize(system.poses, system.edges, system.info)   # only for the (constant) structure + Omega
+        self.nv, self.ne = system.poses.shape[0], system.edges.shape[0]
+        self.st = ctx.assemble_analyze(prob.dim, prob.v0, prob.v1, 3, 3, 3, prob.unary_vertex)
+        self.d_v0 = api.DeviceArray.from_host(ctx, prob.v0.astype(np.int32))
+        self.d_v1 = api.DeviceArray.from_host(ctx, prob.v1.astype(np.int32))
+        self.d_meas = api.DeviceArray.from_host(ctx, np.ascontiguousarray(system.edges[:, 2:5]).ravel())
+        self.d_poses = api.DeviceArray.from_host(ctx, system.poses.ravel())
+        self.d_Om = api.DeviceArray.from_host(ctx, np.ascontiguousarray(prob.Om).ravel())
+        self.d_J0, self.d_J1 = api.DeviceArray(ctx, 9 * self.ne), api.DeviceArray(ctx, 9 * self.ne)
+        self.d_r = api.DeviceArray(ctx, 3 * self.ne)
+        self.d_vals, self.d_eta = api.DeviceArray(ctx, self.st.nvals), api.DeviceArray(ctx, self.st.n)
+        self.analyzed = False
+
+    def step(self):
+        """linearize + assemble + solve; returns (ok, ||dx||); dx stays on the device"""
+        ctx = self.ctx
+        ctx.se2_linearize_device(self.ne, self.d_v0.ptr, self.d_v1.ptr, self.d_poses.ptr, self.d_meas.ptr,
+                                 self.d_J0.ptr, self.d_J1.ptr, self.d_r.ptr)
+        ctx.assemble_device(self.d_J0.ptr, self.d_J1.ptr, self.d_Om.ptr, self.d_r.ptr, 0.0, self.d_vals.ptr, self.d_eta.ptr)
+        if not self.analyzed:
+            ctx.analyze(self.st, api.MODE_AUTO)
+            self.analyzed = True
+        if ctx.factor_solve_device(self.d_vals.ptr, self.d_eta.ptr) != 0:
+            return False, 0.0
+        return True, ctx.se2_update_device(self.nv, self.d_poses.ptr, self.d_eta.ptr, apply=False)
+
+    def apply(self):
+        self.ctx.se2_update_device(self.nv, self.d_poses.ptr, self.d_eta.ptr, apply=True)
+
+    def finish(self, system):
+        system.poses[:] = self.d_poses.download().reshape(-1, 3)
+
+    def close(self):
+        self.ctx.close()
+
+
 class CNonlinearSolver_Lambda:
     """mirror of the reference class for CPoseGraph2D systems. `path` may be replaced by any object with
     solve(problem, first) -> (ok, dx) (the tests drive the loop glue with a CPU checker that way)."""
 
-    def __init__(self, system, path=None, device=0, verbose=False):
+    def __init__(self, system, path=None, device=0, verbose=False, host_jacobians=False):
         self.system = system
-        self.path = path if path is not None else _DevicePath(device)
+        if path is None:  # the product paths need the GPU; host_jacobians keeps the linearization in numpy
+            path = _DevicePath(device) if host_jacobians else _ResidentPath(device)
+        self.path = path
         self.verbose = verbose
         self.n_iterations = 0
         self.last_dx_norm = None
@@ -76,6 +123,19 @@ class CNonlinearSolver_Lambda:
     def Optimize(self, n_max_iteration_num=5, f_min_dx_norm=0.01):
         s = self.system
         self.n_iterations = 0
+        if hasattr(self.path, "step"):  # device-resident iteration
+            self.path.begin(s)
+            for it in range(n_max_iteration_num):
+                ok, norm = self.path.step()
+                self.n_iterations = it + 1
+                self.last_dx_norm = norm
+                if self.verbose:
+                    print("%s, residual norm: %.4f" % ("Cholesky succeeded" if ok else "Cholesky failed", norm))
+                if norm <= f_min_dx_norm or not ok:
+                    break
+                self.path.apply()
+            self.path.finish(s)
+            return self.n_iterations
         for it in range(n_max_iteration_num):
             prob = se2_linearize(s.poses, s.edges, s.info)
             ok, dx = self.path.solve(prob, it == 0)

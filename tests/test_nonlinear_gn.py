@@ -69,9 +69,48 @@ def test_gn_failed_factorization_leaves_the_estimate_unchanged():
 
 
 @pytest.mark.gpu
-def test_gn_on_the_device_matches_the_reference_loop():
+@pytest.mark.parametrize("host_jacobians", [True, False])
+def test_gn_on_the_device_matches_the_reference_loop(host_jacobians):
+    """host_jacobians=False: the whole iteration in HBM (device linearization, assembly, solve, update)"""
     system, g = _system()
-    solver = nonlinear.CNonlinearSolver_Lambda(system)   # device assembly + HIP solve
+    solver = nonlinear.CNonlinearSolver_Lambda(system, host_jacobians=host_jacobians)
     solver.Optimize(int(g["max_iter"]), float(g["threshold"]))
     _check(system, g, solver)
     solver.path.close()
+
+
+@pytest.mark.gpu
+def test_device_linearization_matches_the_host_one():
+    """spp_se2_linearize_device against formats.se2_linearize (analytic Jacobians of 2DSolverBase.h:373-418,
+    as the reference's are): rounding-level agreement, including angle errors across the +-pi cut"""
+    from slam_plus_plus_amd import api
+    from slam_plus_plus_amd.formats import se2_linearize
+    system, g = _system()
+    rng = np.random.default_rng(5)
+    system.poses[:, 2] += rng.uniform(-7, 7, size=system.poses.shape[0])   # headings beyond +-2 pi as well
+    prob = se2_linearize(system.poses, system.edges, system.info)
+    ctx = api.Context(0)
+    ne = system.edges.shape[0]
+    d = dict(v0=api.DeviceArray.from_host(ctx, prob.v0.astype(np.int32)), v1=api.DeviceArray.from_host(ctx, prob.v1.astype(np.int32)),
+             poses=api.DeviceArray.from_host(ctx, system.poses.ravel()),
+             meas=api.DeviceArray.from_host(ctx, np.ascontiguousarray(system.edges[:, 2:5]).ravel()),
+             J0=api.DeviceArray(ctx, 9 * ne), J1=api.DeviceArray(ctx, 9 * ne), r=api.DeviceArray(ctx, 3 * ne))
+    ctx.se2_linearize_device(ne, d["v0"].ptr, d["v1"].ptr, d["poses"].ptr, d["meas"].ptr, d["J0"].ptr, d["J1"].ptr, d["r"].ptr)
+    ctx.synchronize()
+    assert np.allclose(d["J0"].download().reshape(ne, 9), prob.J0, rtol=1e-13, atol=1e-13)
+    assert np.allclose(d["J1"].download().reshape(ne, 9), prob.J1, rtol=1e-13, atol=1e-13)
+    rd = d["r"].download().reshape(ne, 3)
+    assert np.allclose(rd[:, :2], prob.r[:, :2], rtol=1e-12, atol=1e-12)
+    # the angle error agrees modulo the representation of +-pi
+    da = np.abs(rd[:, 2] - prob.r[:, 2])
+    assert np.all(np.minimum(da, np.abs(da - 2 * np.pi)) < 1e-12) and np.all(np.abs(rd[:, 2]) <= np.pi + 1e-12)
+    # update kernel: norm and (+) with the angle clamp
+    dx = rng.normal(size=system.poses.size)
+    ddx = api.DeviceArray.from_host(ctx, dx)
+    assert abs(ctx.se2_update_device(system.poses.shape[0], d["poses"].ptr, ddx.ptr, apply=False) - np.linalg.norm(dx)) < 1e-12 * np.linalg.norm(dx)
+    assert np.array_equal(d["poses"].download(), system.poses.ravel())
+    ctx.se2_update_device(system.poses.shape[0], d["poses"].ptr, ddx.ptr, apply=True)
+    want = system.poses + dx.reshape(-1, 3)
+    want[:, 2] = np.fmod(want[:, 2], 2 * np.pi)
+    assert np.allclose(d["poses"].download().reshape(-1, 3), want, rtol=0, atol=1e-14)
+    ctx.close()
