@@ -177,6 +177,26 @@ int spp_se2_linearize_device(spp_ctx *ctx, int64_t n_edges, const int32_t *d_v0,
 int spp_se2_update_device(spp_ctx *ctx, int64_t n_vertices, double *d_poses, const double *d_dx, int apply,
 	double *h_dx_norm2);
 
+/* ---- on-device geometry of bundle adjustment (CEdgeP2C3D) -------------------------
+ * Cameras: 6 doubles each [t | axis-angle], world -> camera, and 5 constant intrinsics each (fx fy cx cy k:
+ * CVertexCam, include/slam/BA_Types.h); points: XYZ. spp_ba_linearize_device evaluates per observation the
+ * projection of CBAJacobians::Project_P2C (include/slam/BASolverBase.h:260-325), r = z - uv, and its
+ * Jacobians w.r.t. the camera increment of C3DJacobians::Relative_to_Absolute (t' = t + R dt,
+ * R' = R exp(dr), include/slam/3DSolverBase.h:807-850) and w.r.t. the point -- analytically, where the
+ * reference takes forward differences with delta = 1e-9 (BASolverBase.h:559-620): agreement to ~1e-7
+ * relative, the noise of the difference quotients. Output layout = input of spp_assemble_device for the
+ * (6,3,2) edge group: J0 no x (2x6) column-major, J1 no x (2x3), r no x 2. cam_of / pt_of: int32 indices
+ * into the camera / point arrays.
+ * spp_ba_update_device: ||dx||^2 over the n_dx entries of dx -> *h_dx_norm2, and if `apply` camera i
+ * <- camera i (+) dx[cam_dxoff[i] .. +6) (the composition above), point j += dx[pt_dxoff[j] .. +3)
+ * (CVertexCam / CVertexXYZ::Operator_Plus). Synchronizes the stream. */
+int spp_ba_linearize_device(spp_ctx *ctx, int64_t n_obs, const int32_t *d_cam_of, const int32_t *d_pt_of,
+	const double *d_cams, const double *d_intrinsics, const double *d_points, const double *d_measurements,
+	double *d_J0, double *d_J1, double *d_r);
+int spp_ba_update_device(spp_ctx *ctx, int64_t n_cams, double *d_cams, const int64_t *d_cam_dxoff,
+	int64_t n_points, double *d_points, const int64_t *d_pt_dxoff, const double *d_dx, int64_t n_dx, int apply,
+	double *h_dx_norm2);
+
 int spp_device_malloc(spp_ctx *ctx, size_t bytes, void **d_ptr);
 int spp_device_free(spp_ctx *ctx, void *d_ptr);
 int spp_memcpy_h2d(spp_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);

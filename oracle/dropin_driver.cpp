@@ -19,6 +19,11 @@
  *            loop alone (reference linear solver, no GPU): edges, the initial vertex states the reference
  *            derives from them, and the states after Optimize(5, 0.01) (slam_app's defaults,
  *            src/slam_app/Main.cpp:706-707). tools/make_golden_gn.py turns it into tests/golden/*.npz.
+ *        dropin_driver badump n file                     -> golden vectors of the reference's BA edge geometry
+ *            (no solver, no GPU): n random (camera, intrinsics, point) triples with the expectation and the
+ *            two Jacobians of CBAJacobians::Project_P2C (include/slam/BASolverBase.h:559-620, forward
+ *            differences over the SE(3) composition C3DJacobians::Relative_to_Absolute), and the result of
+ *            that composition for a random 6D increment (the camera (+) of CVertexCam::Operator_Plus).
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -219,6 +224,44 @@ int main(int n_arg_num, const char **p_arg_list)
 			return 2;
 		}
 		return Compare("ba cams/points", n_cams, n_points, ref_state, hip_state, 1e-7);
+	}
+	if(n_arg_num > 3 && !strcmp(p_arg_list[1], "badump")) {
+		size_t n = atol(p_arg_list[2]);
+		FILE *p_fw = fopen(p_arg_list[3], "w");
+		if(!p_fw)
+			return 2;
+		fprintf(p_fw, "BAGEOM %lu\n", (unsigned long)n);
+		for(size_t i = 0; i < n; ++ i) {
+			Eigen::Matrix<double, 6, 1> cam, inc, composed;
+			Eigen::Matrix<double, 5, 1> intr;
+			for(int k = 0; k < 3; ++ k) {
+				cam(k) = 2 * RandN();
+				cam(3 + k) = ((i % 7 == 0)? 1e-5 : 0.7) * RandN(); // a few near-identity rotations as well
+				inc(k) = 0.1 * RandN();
+				inc(3 + k) = ((i % 5 == 0)? 1e-7 : 0.05) * RandN();
+			}
+			intr << 400 + 200 * Rand01(), 400 + 200 * Rand01(), 5 * RandN(), 5 * RandN(), ((i % 3 == 0)? 0.0 : 1e-6 * Rand01());
+			Eigen::Vector3d xc(1.5 * RandN(), 1.5 * RandN(), 3 + 5 * Rand01()); // in front of the camera
+			Eigen::Matrix3d R = C3DJacobians::t_AxisAngle_to_RotMatrix(cam.tail<3>());
+			Eigen::Vector3d X = R.transpose() * (xc - cam.head<3>());
+			Eigen::Vector2d uv;
+			Eigen::Matrix<double, 2, 6> H1;
+			Eigen::Matrix<double, 2, 3> H2;
+			CBAJacobians::Project_P2C(cam, intr, X, uv, H1, H2);
+			C3DJacobians::Relative_to_Absolute(cam, inc, composed);
+			fprintf(p_fw, "S");
+			for(int k = 0; k < 6; ++ k) fprintf(p_fw, " %.17g", cam(k));
+			for(int k = 0; k < 5; ++ k) fprintf(p_fw, " %.17g", intr(k));
+			for(int k = 0; k < 3; ++ k) fprintf(p_fw, " %.17g", X(k));
+			for(int k = 0; k < 2; ++ k) fprintf(p_fw, " %.17g", uv(k));
+			for(int c = 0; c < 6; ++ c) for(int r = 0; r < 2; ++ r) fprintf(p_fw, " %.17g", H1(r, c)); // column-major
+			for(int c = 0; c < 3; ++ c) for(int r = 0; r < 2; ++ r) fprintf(p_fw, " %.17g", H2(r, c));
+			for(int k = 0; k < 6; ++ k) fprintf(p_fw, " %.17g", inc(k));
+			for(int k = 0; k < 6; ++ k) fprintf(p_fw, " %.17g", composed(k));
+			fprintf(p_fw, "\n");
+		}
+		fclose(p_fw);
+		return 0;
 	}
 	if(n_arg_num > 4 && !strcmp(p_arg_list[1], "dump")) {
 		size_t n_poses = atol(p_arg_list[2]), n_loops = atol(p_arg_list[3]);

@@ -544,6 +544,36 @@ int spp_se2_update_device(spp_ctx *ctx, int64_t n_vertices, double *d_poses, con
 	SPP_CATCH(ctx)
 }
 
+int spp_ba_linearize_device(spp_ctx *ctx, int64_t n_obs, const int32_t *d_cam_of, const int32_t *d_pt_of,
+	const double *d_cams, const double *d_intrinsics, const double *d_points, const double *d_measurements,
+	double *d_J0, double *d_J1, double *d_r)
+{
+	if(!ctx || n_obs < 0 || !d_cam_of || !d_pt_of || !d_cams || !d_intrinsics || !d_points || !d_measurements ||
+	   !d_J0 || !d_J1 || !d_r)
+		return SPP_E_BADARG;
+	SPP_TRY(ctx)
+	SPP_HIP_CHECK(hipSetDevice(ctx->device));
+	ba_linearize(ctx, n_obs, d_cam_of, d_pt_of, d_cams, d_intrinsics, d_points, d_measurements, d_J0, d_J1, d_r);
+	return SPP_OK;
+	SPP_CATCH(ctx)
+}
+
+int spp_ba_update_device(spp_ctx *ctx, int64_t n_cams, double *d_cams, const int64_t *d_cam_dxoff,
+	int64_t n_points, double *d_points, const int64_t *d_pt_dxoff, const double *d_dx, int64_t n_dx, int apply,
+	double *h_dx_norm2)
+{
+	if(!ctx || n_cams < 0 || n_points < 0 || n_dx < 0 || !d_dx || (n_cams && (!d_cams || !d_cam_dxoff)) ||
+	   (n_points && (!d_points || !d_pt_dxoff)))
+		return SPP_E_BADARG;
+	SPP_TRY(ctx)
+	SPP_HIP_CHECK(hipSetDevice(ctx->device));
+	const double n2 = ba_update(ctx, n_cams, d_cams, d_cam_dxoff, n_points, d_points, d_pt_dxoff, d_dx, n_dx, apply != 0);
+	if(h_dx_norm2)
+		*h_dx_norm2 = n2;
+	return SPP_OK;
+	SPP_CATCH(ctx)
+}
+
 int spp_device_malloc(spp_ctx *ctx, size_t bytes, void **d_ptr)
 {
 	if(!ctx || !d_ptr)

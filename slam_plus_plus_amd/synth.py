@@ -106,7 +106,27 @@ def ba_problem(nc, npts, nobs, seed, heavy_tail=True, interleave=False, spread=0
                    J0=np.ascontiguousarray(Jc.transpose(0, 2, 1)).reshape(nobs, 12),  # col-major 2x6
                    J1=np.ascontiguousarray(Jp.transpose(0, 2, 1)).reshape(nobs, 6),   # col-major 2x3
                    Om=Om, r=r, unary_vertex=int(cam_id[cam_of[0]]), damping=1e-3 * float(max(h0, h1)),
-                   nc=nc, npts=npts)
+                   nc=nc, npts=npts, geometry=dict(R=R, C=C, X=X, f=f, cam_of=cam_of, pt_of=pt_of, cam_id=cam_id, pt_id=pt_id))
+
+
+def ba_states(prob):
+    """The same scene in the REFERENCE's parameterization, as input of spp_ba_linearize_device: cameras
+    [t | axis-angle] (world -> camera, CVertexCam), intrinsics fx fy cx cy k, points, and measurements
+    z = projection + the problem's residual (so that the device residual reproduces prob.r).
+    Returns dict(cams (nc,6), intr (nc,5), points (np,3), meas (no,2), cam_of, pt_of int32,
+    cam_dxoff, pt_dxoff int64: scalar offset of every vertex in the solution vector)."""
+    from scipy.spatial.transform import Rotation
+    g = prob.geometry
+    R, C, X, f = g["R"], g["C"], g["X"], g["f"]
+    nc, npts = R.shape[0], X.shape[0]
+    cams = np.concatenate([-np.einsum("cij,cj->ci", R, C), Rotation.from_matrix(R).as_rotvec()], axis=1)
+    intr = np.tile(np.array([f, f, 0.0, 0.0, 0.0]), (nc, 1))
+    pc = np.einsum("eij,ej->ei", R[g["cam_of"]], X[g["pt_of"]] - C[g["cam_of"]])
+    uv = f * pc[:, :2] / pc[:, 2:3]
+    base = np.zeros(prob.dim.size + 1, dtype=np.int64)
+    np.cumsum(prob.dim, out=base[1:])
+    return dict(cams=cams, intr=intr, points=X.copy(), meas=uv + prob.r, cam_of=g["cam_of"].astype(np.int32),
+                pt_of=g["pt_of"].astype(np.int32), cam_dxoff=base[g["cam_id"]].copy(), pt_dxoff=base[g["pt_id"]].copy())
 
 
 # ------------------------------------------------------------------------------------------------
