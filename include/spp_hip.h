@@ -177,6 +177,17 @@ int spp_se2_linearize_device(spp_ctx *ctx, int64_t n_edges, const int32_t *d_v0,
 int spp_se2_update_device(spp_ctx *ctx, int64_t n_vertices, double *d_poses, const double *d_dx, int apply,
 	double *h_dx_norm2);
 
+/* ---- on-device geometry of 3D pose graphs (CEdgePose3D) ---------------------------
+ * Poses: 6 doubles [t | axis-angle]. Expectation = C3DJacobians::Absolute_to_Relative(v0, v1), error
+ * [z_t - e_t ; log(R(z_r) R(e_r)^T)] (include/slam/SE3_Types.h:264-286), Jacobians w.r.t. the increments of
+ * Relative_to_Absolute (3DSolverBase.h:807-850) -- analytic here, forward differences with delta = 1e-9 in
+ * the reference (:1331-1371). J0, J1: ne x (6x6) column-major, r: ne x 6 (the (6,6,6) group of
+ * spp_assemble_device). spp_se3_update_device: ||dx||^2 and x <- x (+) dx (CVertexPose3D::Operator_Plus). */
+int spp_se3_linearize_device(spp_ctx *ctx, int64_t n_edges, const int32_t *d_v0, const int32_t *d_v1,
+	const double *d_poses, const double *d_measurements, double *d_J0, double *d_J1, double *d_r);
+int spp_se3_update_device(spp_ctx *ctx, int64_t n_vertices, double *d_poses, const double *d_dx, int apply,
+	double *h_dx_norm2);
+
 /* ---- on-device geometry of bundle adjustment (CEdgeP2C3D) -------------------------
  * Cameras: 6 doubles each [t | axis-angle], world -> camera, and 5 constant intrinsics each (fx fy cx cy k:
  * CVertexCam, include/slam/BA_Types.h); points: XYZ. spp_ba_linearize_device evaluates per observation the

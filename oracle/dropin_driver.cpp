@@ -35,6 +35,7 @@
 #include "slam/ConfigSolvers.h"
 #include "slam/SE2_Types.h"
 #include "slam/BA_Types.h"
+#include "slam/SE3_Types.h"
 #include "slam/NonlinearSolver_Lambda_LM.h"
 #include "spp_adapter.h"
 
@@ -224,6 +225,54 @@ int main(int n_arg_num, const char **p_arg_list)
 			return 2;
 		}
 		return Compare("ba cams/points", n_cams, n_points, ref_state, hip_state, 1e-7);
+	}
+	if(n_arg_num > 3 && !strcmp(p_arg_list[1], "se3dump")) {
+		// golden vectors of the reference's SE(3) pose-pose edge geometry (CEdgePose3D,
+		// include/slam/SE3_Types.h:264-286): expectation + forward-difference Jacobians of
+		// C3DJacobians::Absolute_to_Relative (include/slam/3DSolverBase.h:1331-1371), the edge error, and
+		// the vertex (+) (Relative_to_Absolute, :807-850)
+		size_t n = atol(p_arg_list[2]);
+		FILE *p_fw = fopen(p_arg_list[3], "w");
+		if(!p_fw)
+			return 2;
+		fprintf(p_fw, "SE3GEOM %lu\n", (unsigned long)n);
+		typedef Eigen::Matrix<double, 6, 1> V6;
+		typedef Eigen::Matrix<double, 6, 6> M6;
+		for(size_t i = 0; i < n; ++ i) {
+			V6 v1, v2, z, inc, e, err, comp;
+			for(int k = 0; k < 3; ++ k) {
+				v1(k) = 20 * RandN(); v2(k) = v1(k) + 2 * RandN();
+				v1(3 + k) = ((i % 7 == 0)? 1e-5 : 0.9) * RandN();
+				v2(3 + k) = v1(3 + k) + ((i % 5 == 0)? 1e-6 : 0.4) * RandN();
+				inc(k) = 0.3 * RandN(); inc(3 + k) = 0.1 * RandN();
+			}
+			M6 H1, H2;
+			C3DJacobians::Absolute_to_Relative(v1, v2, e, H1, H2);
+			for(int k = 0; k < 3; ++ k) {
+				z(k) = e(k) + 0.05 * RandN(); z(3 + k) = e(3 + k) + 0.02 * RandN();
+			}
+			err.head<3>() = z.head<3>() - e.head<3>();
+			Eigen::Quaterniond pQ, dQ;
+			C3DJacobians::AxisAngle_to_Quat(z.tail<3>(), pQ);
+			C3DJacobians::AxisAngle_to_Quat(e.tail<3>(), dQ);
+			Eigen::Vector3d v_aang;
+			C3DJacobians::Quat_to_AxisAngle(pQ * dQ.conjugate(), v_aang);
+			err.tail<3>() = v_aang;
+			C3DJacobians::Relative_to_Absolute(v1, inc, comp);
+			fprintf(p_fw, "S");
+			for(int k = 0; k < 6; ++ k) fprintf(p_fw, " %.17g", v1(k));
+			for(int k = 0; k < 6; ++ k) fprintf(p_fw, " %.17g", v2(k));
+			for(int k = 0; k < 6; ++ k) fprintf(p_fw, " %.17g", z(k));
+			for(int k = 0; k < 6; ++ k) fprintf(p_fw, " %.17g", e(k));
+			for(int k = 0; k < 6; ++ k) fprintf(p_fw, " %.17g", err(k));
+			for(int c = 0; c < 6; ++ c) for(int r = 0; r < 6; ++ r) fprintf(p_fw, " %.17g", H1(r, c)); // column-major
+			for(int c = 0; c < 6; ++ c) for(int r = 0; r < 6; ++ r) fprintf(p_fw, " %.17g", H2(r, c));
+			for(int k = 0; k < 6; ++ k) fprintf(p_fw, " %.17g", inc(k));
+			for(int k = 0; k < 6; ++ k) fprintf(p_fw, " %.17g", comp(k));
+			fprintf(p_fw, "\n");
+		}
+		fclose(p_fw);
+		return 0;
 	}
 	if(n_arg_num > 3 && !strcmp(p_arg_list[1], "badump")) {
 		size_t n = atol(p_arg_list[2]);

@@ -32,7 +32,7 @@ EXPORTS = [
     "spp_schur_packed_size", "spp_schur_pack", "spp_schur_unpack",
     "spp_assemble_analyze", "spp_assemble_get_structure", "spp_assemble_device", "spp_device_malloc",
     "spp_device_free", "spp_memcpy_h2d", "spp_memcpy_d2h", "spp_memcpy_d2d", "spp_get_phase_ms", "spp_get_dominant_kernel",
-    "spp_microbench_copy", "spp_microbench_mfma_f64", "spp_microbench_ctile", "spp_block_ordering", "spp_set_profiling", "spp_se2_linearize_device", "spp_se2_update_device", "spp_ba_linearize_device", "spp_ba_update_device", "spp_dense_potrf_upper", "spp_dense_posv",
+    "spp_microbench_copy", "spp_microbench_mfma_f64", "spp_microbench_ctile", "spp_block_ordering", "spp_set_profiling", "spp_se2_linearize_device", "spp_se2_update_device", "spp_ba_linearize_device", "spp_ba_update_device", "spp_se3_linearize_device", "spp_se3_update_device", "spp_dense_potrf_upper", "spp_dense_posv",
     "spp_dense_gemm_tn_sub", "spp_version",
 ]
 
@@ -91,6 +91,8 @@ def load_library():
         "spp_set_profiling": (cint, [vp, cint]),
         "spp_se2_linearize_device": (cint, [vp, ctypes.c_int64, vp, vp, vp, vp, vp, vp, vp]),
         "spp_se2_update_device": (cint, [vp, ctypes.c_int64, vp, vp, cint, _c_f64p]),
+        "spp_se3_linearize_device": (cint, [vp, ctypes.c_int64, vp, vp, vp, vp, vp, vp, vp]),
+        "spp_se3_update_device": (cint, [vp, ctypes.c_int64, vp, vp, cint, _c_f64p]),
         "spp_ba_linearize_device": (cint, [vp, ctypes.c_int64, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         "spp_ba_update_device": (cint, [vp, ctypes.c_int64, vp, vp, ctypes.c_int64, vp, vp, vp, ctypes.c_int64, cint, _c_f64p]),
         "spp_dense_potrf_upper": (cint, [vp, vp, i64, i64]),
@@ -221,6 +223,14 @@ class Context:
         """returns ||dx|| (host), applies x <- x (+) dx on the device when `apply`"""
         out = ctypes.c_double()
         self._check(self.lib.spp_se2_update_device(self.h, n_vertices, d_poses, d_dx, 1 if apply else 0, ctypes.byref(out)))
+        return out.value ** 0.5
+
+    def se3_linearize_device(self, n_edges, d_v0, d_v1, d_poses, d_meas, d_J0, d_J1, d_r):
+        return self._check(self.lib.spp_se3_linearize_device(self.h, n_edges, d_v0, d_v1, d_poses, d_meas, d_J0, d_J1, d_r))
+
+    def se3_update_device(self, n_vertices, d_poses, d_dx, apply=True):
+        out = ctypes.c_double()
+        self._check(self.lib.spp_se3_update_device(self.h, n_vertices, d_poses, d_dx, 1 if apply else 0, ctypes.byref(out)))
         return out.value ** 0.5
 
     def ba_linearize_device(self, n_obs, d_cam_of, d_pt_of, d_cams, d_intr, d_points, d_meas, d_J0, d_J1, d_r):

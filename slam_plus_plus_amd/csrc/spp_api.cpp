@@ -544,6 +544,32 @@ int spp_se2_update_device(spp_ctx *ctx, int64_t n_vertices, double *d_poses, con
 	SPP_CATCH(ctx)
 }
 
+int spp_se3_linearize_device(spp_ctx *ctx, int64_t n_edges, const int32_t *d_v0, const int32_t *d_v1,
+	const double *d_poses, const double *d_measurements, double *d_J0, double *d_J1, double *d_r)
+{
+	if(!ctx || n_edges < 0 || !d_v0 || !d_v1 || !d_poses || !d_measurements || !d_J0 || !d_J1 || !d_r)
+		return SPP_E_BADARG;
+	SPP_TRY(ctx)
+	SPP_HIP_CHECK(hipSetDevice(ctx->device));
+	se3_linearize(ctx, n_edges, d_v0, d_v1, d_poses, d_measurements, d_J0, d_J1, d_r);
+	return SPP_OK;
+	SPP_CATCH(ctx)
+}
+
+int spp_se3_update_device(spp_ctx *ctx, int64_t n_vertices, double *d_poses, const double *d_dx, int apply,
+	double *h_dx_norm2)
+{
+	if(!ctx || n_vertices < 0 || !d_poses || !d_dx)
+		return SPP_E_BADARG;
+	SPP_TRY(ctx)
+	SPP_HIP_CHECK(hipSetDevice(ctx->device));
+	const double n2 = se3_update(ctx, n_vertices, d_poses, d_dx, apply != 0);
+	if(h_dx_norm2)
+		*h_dx_norm2 = n2;
+	return SPP_OK;
+	SPP_CATCH(ctx)
+}
+
 int spp_ba_linearize_device(spp_ctx *ctx, int64_t n_obs, const int32_t *d_cam_of, const int32_t *d_pt_of,
 	const double *d_cams, const double *d_intrinsics, const double *d_points, const double *d_measurements,
 	double *d_J0, double *d_J1, double *d_r)

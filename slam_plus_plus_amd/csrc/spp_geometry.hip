@@ -275,6 +275,155 @@ void norm2_partial_kernel(int64_t n, const double *__restrict__ v, double *__res
 		partial[blockIdx.x] = red[0];
 }
 
+// --------------------------------------------------------------------------------------------------
+// SE(3) pose-pose edge CEdgePose3D (vertices [t | axis-angle]). Reference (functional spec):
+//   expectation e = C3DJacobians::Absolute_to_Relative(v1, v2): e_t = R1^T (t2 - t1), e_r = log(R1^T R2)
+//   Jacobians: forward differences (delta = 1e-9) over v (+) d = Relative_to_Absolute(v, d)
+//                                                     include/slam/3DSolverBase.h:1331-1371, :807-850
+//   error: [z_t - e_t ; log(R(z_r) R(e_r)^T)]         include/slam/SE3_Types.h:264-286
+// Here analytic (R_e = R1^T R2, Jr^-1 = inverse right Jacobian of SO(3) at e_r):
+//   d e / d d1 = [ -I   [e_t]x ; 0  -Jr^-1 R_e^T ],   d e / d d2 = [ R_e  0 ; 0  Jr^-1 ]
+// agreeing with the reference's difference quotients to their noise (tests/test_gpu_se3_geometry.py).
+// One thread per edge; J0, J1: 6 x 6 column-major, r: 6.
+// --------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void quat_to_aa(double w, double vx, double vy, double vz, double *a)
+{
+	if(w < 0) {
+		w = -w; vx = -vx; vy = -vy; vz = -vz;
+	}
+	const double vn = sqrt(vx * vx + vy * vy + vz * vz);
+	const double scale = (vn < 1e-12) ? 2.0 : 2.0 * atan2(vn, w) / vn;
+	a[0] = vx * scale; a[1] = vy * scale; a[2] = vz * scale;
+}
+
+__device__ __forceinline__ void quat_mul(const double *p, const double *q, double *o) // o = p q, (w, x, y, z)
+{
+	o[0] = p[0] * q[0] - p[1] * q[1] - p[2] * q[2] - p[3] * q[3];
+	o[1] = p[0] * q[1] + p[1] * q[0] + p[2] * q[3] - p[3] * q[2];
+	o[2] = p[0] * q[2] - p[1] * q[3] + p[2] * q[0] + p[3] * q[1];
+	o[3] = p[0] * q[3] + p[1] * q[2] - p[2] * q[1] + p[3] * q[0];
+}
+
+__global__ __launch_bounds__(256)
+void se3_linearize_kernel(int64_t ne, const int32_t *__restrict__ v0, const int32_t *__restrict__ v1,
+	const double *__restrict__ poses, const double *__restrict__ meas, double *__restrict__ J0,
+	double *__restrict__ J1, double *__restrict__ r)
+{
+	const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if(e >= ne)
+		return;
+	const double *p1 = poses + 6 * (int64_t)v0[e], *p2 = poses + 6 * (int64_t)v1[e], *z = meas + 6 * e;
+	double R1[9], R2[9], Re[9];
+	axis_angle_to_rot(p1 + 3, R1);
+	axis_angle_to_rot(p2 + 3, R2);
+	const double d0 = p2[0] - p1[0], d1 = p2[1] - p1[1], d2 = p2[2] - p1[2];
+	const double et[3] = {R1[0] * d0 + R1[3] * d1 + R1[6] * d2, R1[1] * d0 + R1[4] * d1 + R1[7] * d2,
+		R1[2] * d0 + R1[5] * d1 + R1[8] * d2}; // R1^T (t2 - t1)
+#pragma unroll
+	for(int i = 0; i < 3; ++ i)
+#pragma unroll
+		for(int j = 0; j < 3; ++ j)
+			Re[3 * i + j] = R1[i] * R2[j] + R1[3 + i] * R2[3 + j] + R1[6 + i] * R2[6 + j]; // R1^T R2
+	double q1[4], q2[4], qe[4], er[3];
+	aa_to_quat(p1 + 3, q1);
+	aa_to_quat(p2 + 3, q2);
+	q1[1] = -q1[1]; q1[2] = -q1[2]; q1[3] = -q1[3]; // conjugate
+	quat_mul(q1, q2, qe);
+	quat_to_aa(qe[0], qe[1], qe[2], qe[3], er);
+	// error
+	double qz[4], qec[4] = {qe[0], -qe[1], -qe[2], -qe[3]}, qr[4], rr[3];
+	if(qec[0] < 0) { // the canonical (w >= 0) representative of the expectation, as quat_to_aa / aa_to_quat round-trip
+		qec[0] = -qec[0]; qec[1] = -qec[1]; qec[2] = -qec[2]; qec[3] = -qec[3];
+	}
+	aa_to_quat(z + 3, qz);
+	quat_mul(qz, qec, qr);
+	quat_to_aa(qr[0], qr[1], qr[2], qr[3], rr);
+	double *ro = r + 6 * e;
+	ro[0] = z[0] - et[0]; ro[1] = z[1] - et[1]; ro[2] = z[2] - et[2];
+	ro[3] = rr[0]; ro[4] = rr[1]; ro[5] = rr[2];
+	// Jr^-1(e_r) = I + 1/2 K + c K^2, K = [e_r]x, c = 1/th^2 - (1 + cos th) / (2 th sin th)
+	const double th2 = er[0] * er[0] + er[1] * er[1] + er[2] * er[2], th = sqrt(th2);
+	double c;
+	if(th < 1e-4)
+		c = 1.0 / 12.0 + th2 * (1.0 / 720.0);
+	else {
+		double sn, cs;
+		sincos(th, &sn, &cs);
+		c = 1.0 / th2 - (1.0 + cs) / (2.0 * th * sn);
+	}
+	const double x = er[0], y = er[1], zz = er[2];
+	double Ji[9] = { // I + K/2 + c K^2 (row-major)
+		1 - c * (y * y + zz * zz), -0.5 * zz + c * x * y,      0.5 * y + c * x * zz,
+		0.5 * zz + c * x * y,      1 - c * (x * x + zz * zz),  -0.5 * x + c * y * zz,
+		-0.5 * y + c * x * zz,     0.5 * x + c * y * zz,       1 - c * (x * x + y * y)};
+	double *a = J0 + 36 * e, *b = J1 + 36 * e;
+#pragma unroll
+	for(int q = 0; q < 36; ++ q) {
+		a[q] = 0;
+		b[q] = 0;
+	}
+	// J0 = [ -I  [e_t]x ; 0  -Ji Re^T ]   (column-major: element (row, col) at row + 6 col)
+	a[0 + 6 * 0] = -1; a[1 + 6 * 1] = -1; a[2 + 6 * 2] = -1;
+	a[0 + 6 * 4] = -et[2]; a[0 + 6 * 5] = et[1];
+	a[1 + 6 * 3] = et[2];  a[1 + 6 * 5] = -et[0];
+	a[2 + 6 * 3] = -et[1]; a[2 + 6 * 4] = et[0];
+#pragma unroll
+	for(int i = 0; i < 3; ++ i)
+#pragma unroll
+		for(int j = 0; j < 3; ++ j) {
+			a[(3 + i) + 6 * (3 + j)] = -(Ji[3 * i] * Re[3 * j] + Ji[3 * i + 1] * Re[3 * j + 1] + Ji[3 * i + 2] * Re[3 * j + 2]);
+			b[i + 6 * j] = Re[3 * i + j];
+			b[(3 + i) + 6 * (3 + j)] = Ji[3 * i + j];
+		}
+}
+
+// 6D pose (+): t' = t + R dt, R' = R exp(dr) (CVertexPose3D::Operator_Plus, SE3_Types.h:44-47)
+__global__ __launch_bounds__(256)
+void se3_update_kernel(int64_t nv, double *__restrict__ poses, const double *__restrict__ dx)
+{
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if(i >= nv)
+		return;
+	double *p = poses + 6 * i;
+	const double *d = dx + 6 * i;
+	double R[9], q1[4], q2[4], q[4];
+	axis_angle_to_rot(p + 3, R);
+	p[0] += R[0] * d[0] + R[1] * d[1] + R[2] * d[2];
+	p[1] += R[3] * d[0] + R[4] * d[1] + R[5] * d[2];
+	p[2] += R[6] * d[0] + R[7] * d[1] + R[8] * d[2];
+	aa_to_quat(p + 3, q1);
+	aa_to_quat(d + 3, q2);
+	quat_mul(q1, q2, q);
+	quat_to_aa(q[0], q[1], q[2], q[3], p + 3);
+}
+
+void se3_linearize(spp_ctx *ctx, int64_t ne, const int32_t *d_v0, const int32_t *d_v1, const double *d_poses,
+	const double *d_meas, double *d_J0, double *d_J1, double *d_r)
+{
+	if(!ne)
+		return;
+	hipLaunchKernelGGL(se3_linearize_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, ctx->stream,
+		ne, d_v0, d_v1, d_poses, d_meas, d_J0, d_J1, d_r);
+	SPP_HIP_CHECK(hipGetLastError());
+}
+
+double se3_update(spp_ctx *ctx, int64_t nv, double *d_poses, const double *d_dx, bool apply)
+{
+	if(!nv)
+		return 0;
+	const int64_t n = 6 * nv, nwg = (n + 255) / 256;
+	ctx->geom_partial.reserve((size_t)nwg + 1);
+	hipLaunchKernelGGL(norm2_partial_kernel, dim3((unsigned)nwg), dim3(256), 0, ctx->stream, n, d_dx, ctx->geom_partial.p + 1);
+	hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, ctx->stream, nwg, ctx->geom_partial.p + 1, ctx->geom_partial.p);
+	if(apply)
+		hipLaunchKernelGGL(se3_update_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, ctx->stream, nv, d_poses, d_dx);
+	SPP_HIP_CHECK(hipGetLastError());
+	double h = 0;
+	SPP_HIP_CHECK(hipMemcpyAsync(&h, ctx->geom_partial.p, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+	SPP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	return h;
+}
+
 void ba_linearize(spp_ctx *ctx, int64_t no, const int32_t *d_cam_of, const int32_t *d_pt_of, const double *d_cams,
 	const double *d_intr, const double *d_pts, const double *d_meas, double *d_J0, double *d_J1, double *d_r)
 {

@@ -186,6 +186,9 @@ namespace spp {
 void se2_linearize(spp_ctx *ctx, int64_t ne, const int32_t *d_v0, const int32_t *d_v1, const double *d_poses,
 	const double *d_meas, double *d_J0, double *d_J1, double *d_r);
 double se2_update(spp_ctx *ctx, int64_t nv, double *d_poses, const double *d_dx, bool apply);
+void se3_linearize(spp_ctx *ctx, int64_t ne, const int32_t *d_v0, const int32_t *d_v1, const double *d_poses,
+	const double *d_meas, double *d_J0, double *d_J1, double *d_r);
+double se3_update(spp_ctx *ctx, int64_t nv, double *d_poses, const double *d_dx, bool apply);
 void ba_linearize(spp_ctx *ctx, int64_t no, const int32_t *d_cam_of, const int32_t *d_pt_of, const double *d_cams,
 	const double *d_intr, const double *d_pts, const double *d_meas, double *d_J0, double *d_J1, double *d_r);
 double ba_update(spp_ctx *ctx, int64_t nc, double *d_cams, const int64_t *d_cam_dxoff, int64_t np, double *d_pts,
