@@ -226,6 +226,82 @@ int main(int n_arg_num, const char **p_arg_list)
 		}
 		return Compare("ba cams/points", n_cams, n_points, ref_state, hip_state, 1e-7);
 	}
+	if(n_arg_num > 4 && !strcmp(p_arg_list[1], "dump3")) {
+		// golden vector of the reference's Gauss-Newton loop on a 3D pose graph (poses on rings of a
+		// sphere, odometry along each ring + ring-to-ring edges, the shape of sphere2500 at a size the
+		// CPU handles in a blink): edges, initial states derived by the reference, states after
+		// Optimize(5, 0.01) with the reference's CLinearSolver_UberBlock
+		typedef MakeTypelist(CVertexPose3D) TV3;
+		typedef MakeTypelist(CEdgePose3D) TE3;
+		typedef CFlatSystem<CVertexPose3D, TV3, CEdgePose3D, TE3> CSystem3D;
+		typedef Eigen::Matrix<double, 6, 1> V6;
+		size_t n_rings = atol(p_arg_list[2]), n_per = atol(p_arg_list[3]);
+		std::vector<V6> truth;
+		for(size_t r = 0; r < n_rings; ++ r) {
+			double phi = -1.0 + 2.0 * (r + 0.5) / n_rings; // latitude-like parameter
+			for(size_t k = 0; k < n_per; ++ k) {
+				double th = 6.283185307179586 * k / n_per;
+				V6 v;
+				v << 10 * cos(th) * cos(phi), 10 * sin(th) * cos(phi), 10 * sin(phi), 0.1 * phi, 0.05 * sin(th), th - 3.141592653589793;
+				truth.push_back(v);
+			}
+		}
+		struct TE { size_t a, b; V6 z; };
+		std::vector<TE> edges3;
+		struct L3 { static TE Make(size_t a, size_t b, const std::vector<V6> &t) {
+			TE e; e.a = a; e.b = b;
+			V6 rel;
+			C3DJacobians::Absolute_to_Relative(t[a], t[b], rel);
+			for(int k = 0; k < 3; ++ k) { rel(k) += 0.05 * RandN(); rel(3 + k) += 0.01 * RandN(); }
+			e.z = rel;
+			return e;
+		} };
+		const size_t n_v = truth.size();
+		for(size_t i = 0; i + 1 < n_v; ++ i)
+			edges3.push_back(L3::Make(i, i + 1, truth)); // odometry chain through all rings
+		for(size_t r = 0; r + 1 < n_rings; ++ r)
+			for(size_t k = 0; k < n_per; k += 2)
+				edges3.push_back(L3::Make(r * n_per + k, (r + 1) * n_per + k, truth)); // ring-to-ring closures
+		for(size_t r = 0; r < n_rings; ++ r)
+			edges3.push_back(L3::Make(r * n_per, r * n_per + n_per - 1, truth)); // close every ring
+		CSystem3D system;
+		CNonlinearSolver_Lambda<CSystem3D, CLinearSolver_UberBlock<CSystem3D::_TyHessianMatrixBlockList> > solver(system);
+		Eigen::Matrix<double, 6, 6> information = Eigen::Matrix<double, 6, 6>::Zero();
+		for(int k = 0; k < 3; ++ k) { information(k, k) = 400; information(3 + k, 3 + k) = 10000; }
+		for(size_t i = 0; i < edges3.size(); ++ i)
+			system.r_Add_Edge(CEdgePose3D(edges3[i].a, edges3[i].b, edges3[i].z, information, system));
+		std::vector<double> init, fin;
+		for(size_t i = 0, n = system.r_Vertex_Pool().n_Size(); i < n; ++ i) {
+			Eigen::VectorXd v = system.r_Vertex_Pool()[i].v_State();
+			for(int j = 0; j < v.rows(); ++ j) init.push_back(v(j));
+		}
+		solver.Optimize(5, 0.01);
+		for(size_t i = 0, n = system.r_Vertex_Pool().n_Size(); i < n; ++ i) {
+			Eigen::VectorXd v = system.r_Vertex_Pool()[i].v_State();
+			for(int j = 0; j < v.rows(); ++ j) fin.push_back(v(j));
+		}
+		FILE *p_fw = fopen(p_arg_list[4], "w");
+		if(!p_fw)
+			return 2;
+		fprintf(p_fw, "SE3GN %lu %lu 5 0.01\n", (unsigned long)(init.size() / 6), (unsigned long)edges3.size());
+		for(size_t i = 0; i < edges3.size(); ++ i) {
+			fprintf(p_fw, "E %lu %lu", (unsigned long)edges3[i].a, (unsigned long)edges3[i].b);
+			for(int k = 0; k < 6; ++ k) fprintf(p_fw, " %.17g", edges3[i].z(k));
+			fprintf(p_fw, "\n");
+		}
+		for(size_t i = 0; i + 5 < init.size(); i += 6) {
+			fprintf(p_fw, "I");
+			for(int k = 0; k < 6; ++ k) fprintf(p_fw, " %.17g", init[i + k]);
+			fprintf(p_fw, "\n");
+		}
+		for(size_t i = 0; i + 5 < fin.size(); i += 6) {
+			fprintf(p_fw, "F");
+			for(int k = 0; k < 6; ++ k) fprintf(p_fw, " %.17g", fin[i + k]);
+			fprintf(p_fw, "\n");
+		}
+		fclose(p_fw);
+		return 0;
+	}
 	if(n_arg_num > 3 && !strcmp(p_arg_list[1], "se3dump")) {
 		// golden vectors of the reference's SE(3) pose-pose edge geometry (CEdgePose3D,
 		// include/slam/SE3_Types.h:264-286): expectation + forward-difference Jacobians of

@@ -193,3 +193,57 @@ def se2_linearize(poses, edges, info):
                    J0=np.ascontiguousarray(J0.transpose(0, 2, 1)).reshape(ne, 9),
                    J1=np.ascontiguousarray(J1.transpose(0, 2, 1)).reshape(ne, 9),
                    Om=np.asarray(info, dtype=np.float64).reshape(ne, 9), r=r, unary_vertex=int(v0[0]), damping=0.0)
+
+
+def _hat(v):
+    z = np.zeros(v.shape[0])
+    return np.stack([np.stack([z, -v[:, 2], v[:, 1]], 1), np.stack([v[:, 2], z, -v[:, 0]], 1),
+                     np.stack([-v[:, 1], v[:, 0], z], 1)], 1)
+
+
+def se3_linearize(poses, edges, info):
+    """Hot-path inputs (synth.Problem) of a 3D pose graph at the given estimate. poses (n, 6) [t | axis-angle],
+    edges (m, 8) i j + 6D measurement, info (m, 6, 6). Expectation C3DJacobians::Absolute_to_Relative, error
+    of CEdgePose3D (include/slam/SE3_Types.h:264-286); Jacobians analytic w.r.t. the increments of
+    Relative_to_Absolute (the reference takes forward differences there, 3DSolverBase.h:1331-1371)."""
+    from scipy.spatial.transform import Rotation
+    from .synth import Problem
+    poses = np.asarray(poses, dtype=np.float64)
+    edges = np.asarray(edges, dtype=np.float64)
+    v0, v1 = edges[:, 0].astype(np.int64), edges[:, 1].astype(np.int64)
+    ne = v0.size
+    R1 = Rotation.from_rotvec(poses[v0, 3:]).as_matrix()
+    R2 = Rotation.from_rotvec(poses[v1, 3:]).as_matrix()
+    et = np.einsum("eji,ej->ei", R1, poses[v1, :3] - poses[v0, :3])
+    Re = np.einsum("eji,ejk->eik", R1, R2)
+    er = Rotation.from_matrix(Re).as_rotvec()
+    th = np.linalg.norm(er, axis=1)
+    small = th < 1e-4
+    ths = np.where(small, 1.0, th)
+    c = np.where(small, 1.0 / 12 + th ** 2 / 720, 1 / ths ** 2 - (1 + np.cos(ths)) / (2 * ths * np.sin(ths)))
+    K = _hat(er)
+    Ji = np.eye(3)[None] + 0.5 * K + c[:, None, None] * np.einsum("eij,ejk->eik", K, K)
+    J0 = np.zeros((ne, 6, 6))
+    J1 = np.zeros((ne, 6, 6))
+    J0[:, :3, :3] = -np.eye(3)
+    J0[:, :3, 3:] = _hat(et)
+    J0[:, 3:, 3:] = -np.einsum("eij,ekj->eik", Ji, Re)
+    J1[:, :3, :3] = Re
+    J1[:, 3:, 3:] = Ji
+    z = edges[:, 2:8]
+    rrot = (Rotation.from_rotvec(z[:, 3:]) * Rotation.from_matrix(Re).inv()).as_rotvec()
+    r = np.concatenate([z[:, :3] - et, rrot], axis=1)
+    return Problem(name="se3_graph", dim=np.full(poses.shape[0], 6, dtype=np.int32), v0=v0, v1=v1, d0=6, d1=6, rd=6,
+                   J0=np.ascontiguousarray(J0.transpose(0, 2, 1)).reshape(ne, 36),
+                   J1=np.ascontiguousarray(J1.transpose(0, 2, 1)).reshape(ne, 36),
+                   Om=np.asarray(info, dtype=np.float64).reshape(ne, 36), r=r, unary_vertex=int(v0[0]), damping=0.0)
+
+
+def se3_plus(poses, dx):
+    """x (+) dx of CVertexPose3D (C3DJacobians::Relative_to_Absolute): t + R dt, R exp(dr)"""
+    from scipy.spatial.transform import Rotation
+    R = Rotation.from_rotvec(poses[:, 3:])
+    out = np.empty_like(poses)
+    out[:, :3] = poses[:, :3] + R.apply(dx[:, :3])
+    out[:, 3:] = (R * Rotation.from_rotvec(dx[:, 3:])).as_rotvec()
+    return out

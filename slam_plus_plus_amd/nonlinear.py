@@ -1,7 +1,8 @@
 """Batch Gauss-Newton over the Lambda-solve hot path: the loop glue of the reference's
 CNonlinearSolver_Lambda::Optimize (include/slam/NonlinearSolver_Lambda.h:539-666)
-for 2D pose graphs, with everything per iteration on the device except the Jacobians
-(SURVEY 8d metric 2: "Jacobians on host unless otherwise stated, assembly on device").
+for 2D and 3D pose graphs. Product paths: `_ResidentPath` (the whole iteration in HBM: device
+linearization, assembly, solve, ||dx||, vertex update) and `_DevicePath` (Jacobians on the host --
+SURVEY 8d metric 2's baseline wording -- assembly and solve on the device).
 
 Per iteration, exactly in the reference's order (:605-664):
     linearize at the current estimate  ->  Lambda = J^T Omega J (+ unary factor), eta = J^T Omega r
@@ -16,7 +17,7 @@ import math
 import numpy as np
 
 from . import api
-from .formats import se2_linearize
+from .formats import se2_linearize, se3_linearize, se3_plus
 
 
 class CPoseGraph2D:
@@ -27,10 +28,40 @@ class CPoseGraph2D:
         self.edges = np.asarray(edges, dtype=np.float64)
         self.info = np.asarray(info, dtype=np.float64)
 
+    dof = 3
+
+    def linearize(self):
+        return se2_linearize(self.poses, self.edges, self.info)
+
+    def plus(self, dx):
+        self.poses += dx.reshape(-1, 3)
+        self.poses[:, 2] = np.fmod(self.poses[:, 2], 2 * math.pi)  # f_ClampAngle_2Pi, 2DSolverBase.h:44
+
     def chi2(self):
-        prob = se2_linearize(self.poses, self.edges, self.info)
+        prob = self.linearize()
         om = prob.Om.reshape(-1, 3, 3)
         return float(np.einsum("ei,eij,ej->", prob.r, om, prob.r))
+
+
+class CPoseGraph3D:
+    """3D pose graph: vertex states (n, 6) [t | axis-angle], edges (m, 8) i j + 6D measurement, information (m, 6, 6)
+    (CVertexPose3D / CEdgePose3D, include/slam/SE3_Types.h)"""
+    dof = 6
+
+    def __init__(self, poses, edges, info):
+        self.poses = np.array(poses, dtype=np.float64)
+        self.edges = np.asarray(edges, dtype=np.float64)
+        self.info = np.asarray(info, dtype=np.float64)
+
+    def linearize(self):
+        return se3_linearize(self.poses, self.edges, self.info)
+
+    def plus(self, dx):
+        self.poses = se3_plus(self.poses, dx.reshape(-1, 6))
+
+    def chi2(self):
+        prob = self.linearize()
+        return float(np.einsum("ei,eij,ej->", prob.r, prob.Om.reshape(-1, 6, 6), prob.r))
 
 
 class _DevicePath:
@@ -71,37 +102,40 @@ class _ResidentPath:
 
     def begin(self, system):
         ctx = self.ctx
-        prob = se2_linearize(system.poses, system.edges, system.info)   # only for the (constant) structure + Omega
-        self.nv, self.ne = system.poses.shape[0], system.edges.shape[0]
-        self.st = ctx.assemble_analyze(prob.dim, prob.v0, prob.v1, 3, 3, 3, prob.unary_vertex)
+        prob = system.linearize()   # only for the (constant) structure + Omega
+        self.nv, self.ne, self.dof = system.poses.shape[0], system.edges.shape[0], system.dof
+        self.st = ctx.assemble_analyze(prob.dim, prob.v0, prob.v1, self.dof, self.dof, self.dof, prob.unary_vertex)
+        self._lin = ctx.se2_linearize_device if self.dof == 3 else ctx.se3_linearize_device
+        self._upd = ctx.se2_update_device if self.dof == 3 else ctx.se3_update_device
         self.d_v0 = api.DeviceArray.from_host(ctx, prob.v0.astype(np.int32))
         self.d_v1 = api.DeviceArray.from_host(ctx, prob.v1.astype(np.int32))
-        self.d_meas = api.DeviceArray.from_host(ctx, np.ascontiguousarray(system.edges[:, 2:5]).ravel())
+        self.d_meas = api.DeviceArray.from_host(ctx, np.ascontiguousarray(system.edges[:, 2:2 + self.dof]).ravel())
         self.d_poses = api.DeviceArray.from_host(ctx, system.poses.ravel())
         self.d_Om = api.DeviceArray.from_host(ctx, np.ascontiguousarray(prob.Om).ravel())
-        self.d_J0, self.d_J1 = api.DeviceArray(ctx, 9 * self.ne), api.DeviceArray(ctx, 9 * self.ne)
-        self.d_r = api.DeviceArray(ctx, 3 * self.ne)
+        dd = self.dof * self.dof
+        self.d_J0, self.d_J1 = api.DeviceArray(ctx, dd * self.ne), api.DeviceArray(ctx, dd * self.ne)
+        self.d_r = api.DeviceArray(ctx, self.dof * self.ne)
         self.d_vals, self.d_eta = api.DeviceArray(ctx, self.st.nvals), api.DeviceArray(ctx, self.st.n)
         self.analyzed = False
 
     def step(self):
         """linearize + assemble + solve; returns (ok, ||dx||); dx stays on the device"""
         ctx = self.ctx
-        ctx.se2_linearize_device(self.ne, self.d_v0.ptr, self.d_v1.ptr, self.d_poses.ptr, self.d_meas.ptr,
-                                 self.d_J0.ptr, self.d_J1.ptr, self.d_r.ptr)
+        self._lin(self.ne, self.d_v0.ptr, self.d_v1.ptr, self.d_poses.ptr, self.d_meas.ptr,
+                  self.d_J0.ptr, self.d_J1.ptr, self.d_r.ptr)
         ctx.assemble_device(self.d_J0.ptr, self.d_J1.ptr, self.d_Om.ptr, self.d_r.ptr, 0.0, self.d_vals.ptr, self.d_eta.ptr)
         if not self.analyzed:
             ctx.analyze(self.st, api.MODE_AUTO)
             self.analyzed = True
         if ctx.factor_solve_device(self.d_vals.ptr, self.d_eta.ptr) != 0:
             return False, 0.0
-        return True, ctx.se2_update_device(self.nv, self.d_poses.ptr, self.d_eta.ptr, apply=False)
+        return True, self._upd(self.nv, self.d_poses.ptr, self.d_eta.ptr, apply=False)
 
     def apply(self):
-        self.ctx.se2_update_device(self.nv, self.d_poses.ptr, self.d_eta.ptr, apply=True)
+        self._upd(self.nv, self.d_poses.ptr, self.d_eta.ptr, apply=True)
 
     def finish(self, system):
-        system.poses[:] = self.d_poses.download().reshape(-1, 3)
+        system.poses[:] = self.d_poses.download().reshape(-1, self.dof)
 
     def close(self):
         self.ctx.close()
@@ -137,7 +171,7 @@ class CNonlinearSolver_Lambda:
             self.path.finish(s)
             return self.n_iterations
         for it in range(n_max_iteration_num):
-            prob = se2_linearize(s.poses, s.edges, s.info)
+            prob = s.linearize()
             ok, dx = self.path.solve(prob, it == 0)
             self.n_iterations = it + 1
             norm = float(np.linalg.norm(dx)) if ok else 0.0
@@ -147,8 +181,7 @@ class CNonlinearSolver_Lambda:
             if norm <= f_min_dx_norm:
                 break
             if ok:
-                s.poses += dx.reshape(-1, 3)
-                s.poses[:, 2] = np.fmod(s.poses[:, 2], 2 * math.pi)  # f_ClampAngle_2Pi, 2DSolverBase.h:44
+                s.plus(dx)
             else:
                 break
         return self.n_iterations

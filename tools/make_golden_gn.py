@@ -12,6 +12,22 @@ import tempfile
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if len(sys.argv) > 1 and sys.argv[1] == "se3":      # python tools/make_golden_gn.py se3 6 40
+    n_rings, n_per = int(sys.argv[2]), int(sys.argv[3])
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "gn.txt")
+        subprocess.run([os.path.join(ROOT, "oracle", "_ref", "dropin_driver"), "dump3", str(n_rings), str(n_per), path], check=True)
+        rows = {"E": [], "I": [], "F": []}
+        for ln in open(path):
+            t = ln.split()
+            if t[0] in rows:
+                rows[t[0]].append([float(x) for x in t[1:]])
+    edges, init, final = np.array(rows["E"]), np.array(rows["I"]), np.array(rows["F"])
+    out = os.path.join(ROOT, "tests", "golden", "se3_gn_%d.npz" % init.shape[0])
+    np.savez_compressed(out, edges=edges, info_diag=np.array([400.0] * 3 + [10000.0] * 3), init=init, final=final,
+                        max_iter=5, threshold=0.01)
+    print(out, edges.shape, init.shape, "moved by", np.abs(final - init).max())
+    sys.exit(0)
 n_poses = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 n_loops = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 with tempfile.TemporaryDirectory() as td:
