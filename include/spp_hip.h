@@ -208,6 +208,17 @@ int spp_ba_update_device(spp_ctx *ctx, int64_t n_cams, double *d_cams, const int
 	int64_t n_points, double *d_points, const int64_t *d_pt_dxoff, const double *d_dx, int64_t n_dx, int apply,
 	double *h_dx_norm2);
 
+/* ---- scalars of the Levenberg-Marquardt control (include/slam/NonlinearSolver_Lambda_LM.h) ----------
+ * chi2 = sum_e r_e^T Omega_e r_e (f_Error, :1078-1095); the largest diagonal entry of any vertex Hessian
+ * J_i^T Omega J_i over all edges (f_InitialDamping multiplies it by tau = 1e-3, :151-199); the denominator
+ * dx . (alpha dx + eta) of the gain ratio (Aftermath, :204-222). Device inputs, host outputs, deterministic
+ * reductions; each call synchronizes the stream. rd / (d0, d1): the edge group of spp_assemble_analyze. */
+int spp_edge_chi2_device(spp_ctx *ctx, int64_t n_edges, int rd, const double *d_r, const double *d_Omega, double *h_chi2);
+int spp_edge_hessian_maxdiag_device(spp_ctx *ctx, int64_t n_edges, int rd, int d0, int d1, const double *d_J0,
+	const double *d_J1, const double *d_Omega, double *h_max);
+int spp_lm_gain_denominator_device(spp_ctx *ctx, int64_t n, const double *d_dx, const double *d_eta, double alpha,
+	double *h_out);
+
 int spp_device_malloc(spp_ctx *ctx, size_t bytes, void **d_ptr);
 int spp_device_free(spp_ctx *ctx, void *d_ptr);
 int spp_memcpy_h2d(spp_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);

@@ -226,6 +226,49 @@ int main(int n_arg_num, const char **p_arg_list)
 		}
 		return Compare("ba cams/points", n_cams, n_points, ref_state, hip_state, 1e-7);
 	}
+	if(n_arg_num > 5 && !strcmp(p_arg_list[1], "lmdump")) {
+		// golden vector of the reference's LEVENBERG-MARQUARDT loop on a generated BA problem (reference
+		// linear solver behind the reference's Schur complement, CPU only): the problem, and the vertex
+		// states after Optimize(n_iter, 0.01)
+		size_t n_cams = atol(p_arg_list[2]), n_points = atol(p_arg_list[3]), n_iters = atol(p_arg_list[4]);
+		TBAProblem problem;
+		Generate_BA(n_cams, n_points, problem);
+		CBASystemType system;
+		typedef CLinearSolver_UberBlock<CBASystemType::_TyHessianMatrixBlockList> CLinSolver;
+		CNonlinearSolver_Lambda_LM<CBASystemType, CLinSolver> solver(system, TIncrementalSolveSetting(),
+			TMarginalsComputationPolicy(), false, CLinSolver(), true);
+		for(size_t i = 0; i < n_cams; ++ i)
+			system.r_Get_Vertex<CVertexCam>(i, problem.cams[i]);
+		for(size_t j = 0; j < problem.points.size(); ++ j)
+			system.r_Get_Vertex<CVertexXYZ>(n_cams + j, problem.points[j]);
+		for(size_t i = 0; i < problem.obs.size(); ++ i)
+			system.r_Add_Edge(CEdgeP2C3D(n_cams + problem.obs[i].n_pt, problem.obs[i].n_cam, problem.obs[i].z,
+				Eigen::Matrix2d::Identity(), system));
+		solver.Optimize(n_iters, 0.01);
+		FILE *p_fw = fopen(p_arg_list[5], "w");
+		if(!p_fw)
+			return 2;
+		fprintf(p_fw, "BALM %lu %lu %lu %lu\n", (unsigned long)n_cams, (unsigned long)problem.points.size(),
+			(unsigned long)problem.obs.size(), (unsigned long)n_iters);
+		for(size_t i = 0; i < n_cams; ++ i) {
+			fprintf(p_fw, "C");
+			for(int k = 0; k < 11; ++ k) fprintf(p_fw, " %.17g", problem.cams[i](k));
+			fprintf(p_fw, "\n");
+		}
+		for(size_t j = 0; j < problem.points.size(); ++ j)
+			fprintf(p_fw, "P %.17g %.17g %.17g\n", problem.points[j](0), problem.points[j](1), problem.points[j](2));
+		for(size_t i = 0; i < problem.obs.size(); ++ i)
+			fprintf(p_fw, "O %lu %lu %.17g %.17g\n", (unsigned long)problem.obs[i].n_cam, (unsigned long)problem.obs[i].n_pt,
+				problem.obs[i].z(0), problem.obs[i].z(1));
+		for(size_t i = 0, n = system.r_Vertex_Pool().n_Size(); i < n; ++ i) {
+			Eigen::VectorXd v = system.r_Vertex_Pool()[i].v_State();
+			fprintf(p_fw, "F");
+			for(int j = 0; j < v.rows(); ++ j) fprintf(p_fw, " %.17g", v(j));
+			fprintf(p_fw, "\n");
+		}
+		fclose(p_fw);
+		return 0;
+	}
 	if(n_arg_num > 4 && !strcmp(p_arg_list[1], "dump3")) {
 		// golden vector of the reference's Gauss-Newton loop on a 3D pose graph (poses on rings of a
 		// sphere, odometry along each ring + ring-to-ring edges, the shape of sphere2500 at a size the

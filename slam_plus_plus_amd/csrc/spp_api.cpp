@@ -600,6 +600,41 @@ int spp_ba_update_device(spp_ctx *ctx, int64_t n_cams, double *d_cams, const int
 	SPP_CATCH(ctx)
 }
 
+int spp_edge_chi2_device(spp_ctx *ctx, int64_t n_edges, int rd, const double *d_r, const double *d_Omega, double *h_chi2)
+{
+	if(!ctx || n_edges < 0 || !d_r || !d_Omega || !h_chi2)
+		return SPP_E_BADARG;
+	SPP_TRY(ctx)
+	SPP_HIP_CHECK(hipSetDevice(ctx->device));
+	*h_chi2 = edge_chi2(ctx, n_edges, rd, d_r, d_Omega);
+	return SPP_OK;
+	SPP_CATCH(ctx)
+}
+
+int spp_edge_hessian_maxdiag_device(spp_ctx *ctx, int64_t n_edges, int rd, int d0, int d1, const double *d_J0,
+	const double *d_J1, const double *d_Omega, double *h_max)
+{
+	if(!ctx || n_edges < 0 || !d_J0 || !d_J1 || !d_Omega || !h_max)
+		return SPP_E_BADARG;
+	SPP_TRY(ctx)
+	SPP_HIP_CHECK(hipSetDevice(ctx->device));
+	*h_max = edge_hessian_maxdiag(ctx, n_edges, rd, d0, d1, d_J0, d_J1, d_Omega);
+	return SPP_OK;
+	SPP_CATCH(ctx)
+}
+
+int spp_lm_gain_denominator_device(spp_ctx *ctx, int64_t n, const double *d_dx, const double *d_eta, double alpha,
+	double *h_out)
+{
+	if(!ctx || n < 0 || !d_dx || !d_eta || !h_out)
+		return SPP_E_BADARG;
+	SPP_TRY(ctx)
+	SPP_HIP_CHECK(hipSetDevice(ctx->device));
+	*h_out = lm_gain_denominator(ctx, n, d_dx, d_eta, alpha);
+	return SPP_OK;
+	SPP_CATCH(ctx)
+}
+
 int spp_device_malloc(spp_ctx *ctx, size_t bytes, void **d_ptr)
 {
 	if(!ctx || !d_ptr)

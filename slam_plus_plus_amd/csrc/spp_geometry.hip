@@ -397,6 +397,172 @@ void se3_update_kernel(int64_t nv, double *__restrict__ poses, const double *__r
 	quat_to_aa(q[0], q[1], q[2], q[3], p + 3);
 }
 
+// --------------------------------------------------------------------------------------------------
+// Scalars the Levenberg-Marquardt control needs (reference include/slam/NonlinearSolver_Lambda_LM.h):
+//   chi2 = sum_e r_e^T Omega_e r_e                                  (f_Error, :1078-1095)
+//   alpha0 input = max_e max diag(J_i^T Omega J_i)                  (f_InitialDamping, :151-199)
+//   gain denominator = dx . (alpha dx + eta)                        (Aftermath, :204-222)
+// Deterministic two-stage reductions (per-workgroup partials in a fixed order, then one workgroup).
+// --------------------------------------------------------------------------------------------------
+template <int RD>
+__global__ __launch_bounds__(256)
+void edge_chi2_kernel(int64_t ne, const double *__restrict__ r, const double *__restrict__ Om, double *__restrict__ partial)
+{
+	__shared__ double red[256];
+	const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	double s = 0;
+	if(e < ne) {
+		const double *re = r + RD * e, *oe = Om + RD * RD * e;
+#pragma unroll
+		for(int i = 0; i < RD; ++ i) {
+			double t = 0;
+#pragma unroll
+			for(int j = 0; j < RD; ++ j)
+				t += oe[i + RD * j] * re[j];
+			s += re[i] * t;
+		}
+	}
+	red[threadIdx.x] = s;
+	__syncthreads();
+	for(int off = 128; off > 0; off >>= 1) {
+		if((int)threadIdx.x < off)
+			red[threadIdx.x] += red[threadIdx.x + off];
+		__syncthreads();
+	}
+	if(threadIdx.x == 0)
+		partial[blockIdx.x] = red[0];
+}
+
+template <int RD, int D>
+__device__ __forceinline__ double max_hdiag(const double *J, const double *Om)
+{
+	double m = 0;
+#pragma unroll
+	for(int c = 0; c < D; ++ c) { // (J^T Omega J)_cc, J: RD x D column-major
+		double s = 0;
+#pragma unroll
+		for(int i = 0; i < RD; ++ i) {
+			double t = 0;
+#pragma unroll
+			for(int j = 0; j < RD; ++ j)
+				t += Om[i + RD * j] * J[j + RD * c];
+			s += J[i + RD * c] * t;
+		}
+		m = fmax(m, s);
+	}
+	return m;
+}
+
+template <int RD, int D0, int D1>
+__global__ __launch_bounds__(256)
+void edge_maxdiag_kernel(int64_t ne, const double *__restrict__ J0, const double *__restrict__ J1,
+	const double *__restrict__ Om, double *__restrict__ partial)
+{
+	__shared__ double red[256];
+	const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	double m = 0;
+	if(e < ne)
+		m = fmax(max_hdiag<RD, D0>(J0 + RD * D0 * e, Om + RD * RD * e), max_hdiag<RD, D1>(J1 + RD * D1 * e, Om + RD * RD * e));
+	red[threadIdx.x] = m;
+	__syncthreads();
+	for(int off = 128; off > 0; off >>= 1) {
+		if((int)threadIdx.x < off)
+			red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + off]);
+		__syncthreads();
+	}
+	if(threadIdx.x == 0)
+		partial[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256)
+void max_partials_kernel(int64_t n, const double *__restrict__ partial, double *__restrict__ out)
+{
+	__shared__ double red[256];
+	double m = 0;
+	for(int64_t i = threadIdx.x; i < n; i += 256)
+		m = fmax(m, partial[i]);
+	red[threadIdx.x] = m;
+	__syncthreads();
+	for(int off = 128; off > 0; off >>= 1) {
+		if((int)threadIdx.x < off)
+			red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + off]);
+		__syncthreads();
+	}
+	if(threadIdx.x == 0)
+		out[0] = red[0];
+}
+
+__global__ __launch_bounds__(256)
+void gain_partial_kernel(int64_t n, const double *__restrict__ dx, const double *__restrict__ rhs, double alpha,
+	double *__restrict__ partial)
+{
+	__shared__ double red[256];
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	red[threadIdx.x] = (i < n) ? dx[i] * (alpha * dx[i] + rhs[i]) : 0.0;
+	__syncthreads();
+	for(int off = 128; off > 0; off >>= 1) {
+		if((int)threadIdx.x < off)
+			red[threadIdx.x] += red[threadIdx.x + off];
+		__syncthreads();
+	}
+	if(threadIdx.x == 0)
+		partial[blockIdx.x] = red[0];
+}
+
+static double fetch_scalar(spp_ctx *ctx)
+{
+	double h = 0;
+	SPP_HIP_CHECK(hipGetLastError());
+	SPP_HIP_CHECK(hipMemcpyAsync(&h, ctx->geom_partial.p, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+	SPP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	return h;
+}
+
+double edge_chi2(spp_ctx *ctx, int64_t ne, int rd, const double *d_r, const double *d_Om)
+{
+	if(!ne)
+		return 0;
+	const int64_t nwg = (ne + 255) / 256;
+	ctx->geom_partial.reserve((size_t)nwg + 1);
+	double *part = ctx->geom_partial.p + 1;
+	const dim3 g((unsigned)nwg), b(256);
+	if(rd == 2) hipLaunchKernelGGL((edge_chi2_kernel<2>), g, b, 0, ctx->stream, ne, d_r, d_Om, part);
+	else if(rd == 3) hipLaunchKernelGGL((edge_chi2_kernel<3>), g, b, 0, ctx->stream, ne, d_r, d_Om, part);
+	else if(rd == 6) hipLaunchKernelGGL((edge_chi2_kernel<6>), g, b, 0, ctx->stream, ne, d_r, d_Om, part);
+	else throw Error(SPP_E_UNSUPPORTED, "chi2: residual dimension must be 2, 3 or 6");
+	hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, ctx->stream, nwg, part, ctx->geom_partial.p);
+	return fetch_scalar(ctx);
+}
+
+double edge_hessian_maxdiag(spp_ctx *ctx, int64_t ne, int rd, int d0, int d1, const double *d_J0, const double *d_J1,
+	const double *d_Om)
+{
+	if(!ne)
+		return 0;
+	const int64_t nwg = (ne + 255) / 256;
+	ctx->geom_partial.reserve((size_t)nwg + 1);
+	double *part = ctx->geom_partial.p + 1;
+	const dim3 g((unsigned)nwg), b(256);
+	if(rd == 2 && d0 == 6 && d1 == 3) hipLaunchKernelGGL((edge_maxdiag_kernel<2, 6, 3>), g, b, 0, ctx->stream, ne, d_J0, d_J1, d_Om, part);
+	else if(rd == 3 && d0 == 3 && d1 == 3) hipLaunchKernelGGL((edge_maxdiag_kernel<3, 3, 3>), g, b, 0, ctx->stream, ne, d_J0, d_J1, d_Om, part);
+	else if(rd == 6 && d0 == 6 && d1 == 6) hipLaunchKernelGGL((edge_maxdiag_kernel<6, 6, 6>), g, b, 0, ctx->stream, ne, d_J0, d_J1, d_Om, part);
+	else throw Error(SPP_E_UNSUPPORTED, "max Hessian diagonal: edge group must be (2,6,3), (3,3,3) or (6,6,6)");
+	hipLaunchKernelGGL(max_partials_kernel, dim3(1), dim3(256), 0, ctx->stream, nwg, part, ctx->geom_partial.p);
+	return fetch_scalar(ctx);
+}
+
+double lm_gain_denominator(spp_ctx *ctx, int64_t n, const double *d_dx, const double *d_rhs, double alpha)
+{
+	if(!n)
+		return 0;
+	const int64_t nwg = (n + 255) / 256;
+	ctx->geom_partial.reserve((size_t)nwg + 1);
+	double *part = ctx->geom_partial.p + 1;
+	hipLaunchKernelGGL(gain_partial_kernel, dim3((unsigned)nwg), dim3(256), 0, ctx->stream, n, d_dx, d_rhs, alpha, part);
+	hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, ctx->stream, nwg, part, ctx->geom_partial.p);
+	return fetch_scalar(ctx);
+}
+
 void se3_linearize(spp_ctx *ctx, int64_t ne, const int32_t *d_v0, const int32_t *d_v1, const double *d_poses,
 	const double *d_meas, double *d_J0, double *d_J1, double *d_r)
 {

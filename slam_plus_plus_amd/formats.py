@@ -247,3 +247,41 @@ def se3_plus(poses, dx):
     out[:, :3] = poses[:, :3] + R.apply(dx[:, :3])
     out[:, 3:] = (R * Rotation.from_rotvec(dx[:, 3:])).as_rotvec()
     return out
+
+
+def ba_linearize(cams, intr, points, obs, cam_id=None, pt_id=None):
+    """Hot-path inputs (synth.Problem) of a bundle adjustment at the given estimate, reference parameterization:
+    cams (nc, 6) [t | axis-angle] world -> camera, intr (nc, 5) fx fy cx cy k, points (np, 3), obs (no, 4)
+    cam pt u v. Model and increments of CBAJacobians::Project_P2C (include/slam/BASolverBase.h:260-325,559-620;
+    analytic where the reference takes forward differences). Vertex ids: cameras 0..nc-1, points nc.. unless
+    cam_id / pt_id say otherwise."""
+    from scipy.spatial.transform import Rotation
+    from .synth import Problem
+    cams, intr, points, obs = (np.asarray(a, dtype=np.float64) for a in (cams, intr, points, obs))
+    nc, npts, no = cams.shape[0], points.shape[0], obs.shape[0]
+    co, po = obs[:, 0].astype(np.int64), obs[:, 1].astype(np.int64)
+    cam_id = np.arange(nc) if cam_id is None else np.asarray(cam_id)
+    pt_id = nc + np.arange(npts) if pt_id is None else np.asarray(pt_id)
+    R = Rotation.from_rotvec(cams[:, 3:]).as_matrix()[co]
+    X = points[po]
+    x = np.einsum("eij,ej->ei", R, X) + cams[co, :3]
+    fx, fy, cx, cy = (intr[co, i] for i in range(4))
+    k = intr[co, 4] / (0.5 * (fx + fy))
+    iz = 1.0 / x[:, 2]
+    d = np.stack([fx * x[:, 0] * iz, fy * x[:, 1] * iz], axis=1)
+    r2 = (d ** 2).sum(axis=1)
+    g = 1 + r2 * k
+    uv = np.stack([cx, cy], axis=1) + g[:, None] * d
+    Jd = np.zeros((no, 2, 3))
+    Jd[:, 0, 0], Jd[:, 0, 2] = fx * iz, -fx * x[:, 0] * iz * iz
+    Jd[:, 1, 1], Jd[:, 1, 2] = fy * iz, -fy * x[:, 1] * iz * iz
+    D = g[:, None, None] * np.eye(2)[None] + 2 * k[:, None, None] * np.einsum("ei,ej->eij", d, d)
+    PR = np.einsum("eij,ejk,ekl->eil", D, Jd, R)
+    J0 = np.concatenate([PR, -np.einsum("eij,ejk->eik", PR, _hat(X))], axis=2)
+    dim = np.empty(nc + npts, dtype=np.int32)
+    dim[cam_id] = 6
+    dim[pt_id] = 3
+    return Problem(name="ba", dim=dim, v0=cam_id[co], v1=pt_id[po], d0=6, d1=3, rd=2,
+                   J0=np.ascontiguousarray(J0.transpose(0, 2, 1)).reshape(no, 12),
+                   J1=np.ascontiguousarray(PR.transpose(0, 2, 1)).reshape(no, 6),
+                   Om=np.tile(np.eye(2).ravel(), (no, 1)), r=obs[:, 2:4] - uv, unary_vertex=int(cam_id[co[0]]), damping=0.0)

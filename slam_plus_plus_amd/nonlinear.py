@@ -17,7 +17,7 @@ import math
 import numpy as np
 
 from . import api
-from .formats import se2_linearize, se3_linearize, se3_plus
+from .formats import se2_linearize, se3_linearize, se3_plus, ba_linearize
 
 
 class CPoseGraph2D:
@@ -184,4 +184,175 @@ class CNonlinearSolver_Lambda:
                 s.plus(dx)
             else:
                 break
+        return self.n_iterations
+
+
+# --------------------------------------------------------------------------------------------------
+# Levenberg-Marquardt (what slam_app silently uses for every BA input, src/slam_app/Main.cpp:203-208)
+# --------------------------------------------------------------------------------------------------
+class CBundleAdjustment:
+    """BA 'system': cams (nc, 6) [t | axis-angle] world -> camera, intr (nc, 5), points (np, 3), obs (no, 4)
+    cam pt u v. Vertex ids: cameras 0..nc-1, points nc.. (the layout of the reference's BA example)."""
+
+    def __init__(self, cams, intr, points, obs):
+        self.cams = np.array(cams, dtype=np.float64)
+        self.intr = np.asarray(intr, dtype=np.float64)
+        self.points = np.array(points, dtype=np.float64)
+        self.obs = np.asarray(obs, dtype=np.float64)
+
+    def linearize(self):
+        return ba_linearize(self.cams, self.intr, self.points, self.obs)
+
+    def chi2(self):
+        r = self.linearize().r
+        return float((r ** 2).sum())
+
+    def state(self):
+        return self.cams.copy(), self.points.copy()
+
+    def set_state(self, st):
+        self.cams, self.points = st[0].copy(), st[1].copy()
+
+    def plus(self, dx):
+        nc = self.cams.shape[0]
+        self.cams = se3_plus(self.cams, dx[:6 * nc].reshape(nc, 6))
+        self.points = self.points + dx[6 * nc:].reshape(-1, 3)
+
+
+class _ResidentBAPath:
+    """LM iteration pieces in HBM: spp_ba_linearize_device, spp_assemble_device (damping alpha),
+    spp_factor_solve_device, spp_ba_update_device, chi2 / alpha0 / gain-ratio reductions."""
+
+    def __init__(self, device=0):
+        self.ctx = api.Context(device)
+
+    def begin(self, system):
+        ctx, s = self.ctx, system
+        prob = s.linearize()   # structure only
+        self.no, self.nc, self.np = s.obs.shape[0], s.cams.shape[0], s.points.shape[0]
+        self.st = ctx.assemble_analyze(prob.dim, prob.v0, prob.v1, 6, 3, 2, prob.unary_vertex)
+        up = lambda a: api.DeviceArray.from_host(ctx, np.ascontiguousarray(a).ravel())
+        self.d_cam_of, self.d_pt_of = up(s.obs[:, 0].astype(np.int32)), up(s.obs[:, 1].astype(np.int32))
+        self.d_cams, self.d_intr, self.d_pts = up(s.cams), up(s.intr), up(s.points)
+        self.d_meas, self.d_Om = up(s.obs[:, 2:4]), up(prob.Om)
+        self.d_cam_off = up(6 * np.arange(self.nc, dtype=np.int64))
+        self.d_pt_off = up(6 * self.nc + 3 * np.arange(self.np, dtype=np.int64))
+        self.d_J0, self.d_J1 = api.DeviceArray(ctx, 12 * self.no), api.DeviceArray(ctx, 6 * self.no)
+        self.d_r = api.DeviceArray(ctx, 2 * self.no)
+        self.d_vals, self.d_eta, self.d_dx = (api.DeviceArray(ctx, self.st.nvals), api.DeviceArray(ctx, self.st.n),
+                                              api.DeviceArray(ctx, self.st.n))
+        self.s_cams, self.s_pts = api.DeviceArray(ctx, 6 * self.nc), api.DeviceArray(ctx, 3 * self.np)
+        self.analyzed = False
+
+    def linearize(self):
+        self.ctx.ba_linearize_device(self.no, self.d_cam_of.ptr, self.d_pt_of.ptr, self.d_cams.ptr, self.d_intr.ptr,
+                                     self.d_pts.ptr, self.d_meas.ptr, self.d_J0.ptr, self.d_J1.ptr, self.d_r.ptr)
+
+    def chi2(self):
+        """error at the CURRENT state (re-evaluates the residuals; J of the last linearization is overwritten too,
+        which the loop accounts for by re-linearizing after a rejected step is rolled back)"""
+        self.linearize()
+        return self.ctx.edge_chi2_device(self.no, 2, self.d_r.ptr, self.d_Om.ptr)
+
+    def max_hessian_diag(self):
+        return self.ctx.edge_hessian_maxdiag_device(self.no, 2, 6, 3, self.d_J0.ptr, self.d_J1.ptr, self.d_Om.ptr)
+
+    def solve(self, alpha):
+        ctx = self.ctx
+        ctx.assemble_device(self.d_J0.ptr, self.d_J1.ptr, self.d_Om.ptr, self.d_r.ptr, alpha, self.d_vals.ptr, self.d_eta.ptr)
+        if not self.analyzed:
+            ctx.analyze(self.st, api.MODE_AUTO)
+            self.analyzed = True
+        self.d_dx.copy_from(self.d_eta)
+        if ctx.factor_solve_device(self.d_vals.ptr, self.d_dx.ptr) != 0:
+            return False, 0.0
+        return True, ctx.ba_update_device(self.nc, self.d_cams.ptr, self.d_cam_off.ptr, self.np, self.d_pts.ptr,
+                                          self.d_pt_off.ptr, self.d_dx.ptr, self.st.n, apply=False)
+
+    def gain_denominator(self, alpha):
+        return self.ctx.lm_gain_denominator_device(self.st.n, self.d_dx.ptr, self.d_eta.ptr, alpha)
+
+    def save(self):
+        self.s_cams.copy_from(self.d_cams)
+        self.s_pts.copy_from(self.d_pts)
+
+    def restore(self):
+        self.d_cams.copy_from(self.s_cams)
+        self.d_pts.copy_from(self.s_pts)
+
+    def apply(self):
+        self.ctx.ba_update_device(self.nc, self.d_cams.ptr, self.d_cam_off.ptr, self.np, self.d_pts.ptr, self.d_pt_off.ptr,
+                                  self.d_dx.ptr, self.st.n, apply=True)
+
+    def finish(self, system):
+        system.cams = self.d_cams.download().reshape(-1, 6)
+        system.points = self.d_pts.download().reshape(-1, 3)
+
+    def close(self):
+        self.ctx.close()
+
+
+class CNonlinearSolver_Lambda_LM:
+    """Mirror of CNonlinearSolver_Lambda_LM::Optimize (include/slam/NonlinearSolver_Lambda_LM.h:796-1135) with
+    the Levenberg trust-region policy of :151-222:
+        alpha0 = 1e-3 * largest diagonal entry of any vertex Hessian;  last = chi2(x)
+        loop: Lambda = J^T Omega J + alpha I (re-linearized only after an accepted step), dx = Lambda^-1 eta,
+              stop if ||dx|| <= threshold; save x; x <- x (+) dx; err = chi2(x);
+              rho = (last - err) / (dx . (alpha dx + eta));
+              rho > 0: alpha *= max(1/3, 1 - (2 rho - 1)^3), nu = 2, last = err
+              else   : alpha *= nu, nu *= 2, restore x, and the iteration budget grows by one (at most 10 times)
+    `path`: _ResidentBAPath (default, GPU) or any object with the same methods (tests inject a host path)."""
+
+    def __init__(self, system, path=None, device=0, verbose=False):
+        self.system = system
+        self.path = path if path is not None else _ResidentBAPath(device)
+        self.verbose = verbose
+        self.n_iterations = 0
+        self.alpha = None
+        self.chi2_history = []
+
+    def Optimize(self, n_max_iteration_num=5, f_min_dx_norm=0.01):
+        p = self.path
+        p.begin(self.system)
+        p.linearize()
+        alpha = 1e-3 * p.max_hessian_diag()
+        nu = 2.0
+        last = p.chi2()
+        self.chi2_history = [last]
+        fail = 10
+        dirty = False       # J / r on the device are those of the current state (chi2 re-linearized it)
+        it = 0
+        while it < n_max_iteration_num:
+            if it and dirty:
+                p.linearize()
+            dirty = False
+            ok, norm = p.solve(alpha)
+            self.n_iterations = it + 1
+            if not ok:
+                break
+            if self.verbose:
+                print("iter %d: alpha %.6g ||dx|| %.6g" % (it, alpha, norm))
+            if norm <= f_min_dx_norm:
+                break
+            p.save()
+            denom = p.gain_denominator(alpha)
+            p.apply()
+            err = p.chi2()          # leaves J / r of the NEW state on the device
+            rho = (last - err) / denom
+            if rho > 0:
+                alpha *= max(1.0 / 3.0, 1.0 - (2.0 * rho - 1.0) ** 3)
+                nu = 2.0
+                last = err
+                self.chi2_history.append(err)
+            else:
+                alpha *= nu
+                nu *= 2.0
+                p.restore()
+                dirty = True    # the device holds the linearization of the rejected state: redo it at the restored one
+                if fail > 0:
+                    fail -= 1
+                    n_max_iteration_num += 1
+            it += 1
+        self.alpha = alpha
+        p.finish(self.system)
         return self.n_iterations

@@ -28,6 +28,24 @@ if len(sys.argv) > 1 and sys.argv[1] == "se3":      # python tools/make_golden_g
                         max_iter=5, threshold=0.01)
     print(out, edges.shape, init.shape, "moved by", np.abs(final - init).max())
     sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "lm":       # python tools/make_golden_gn.py lm 12 300 5
+    n_cams, n_points, n_iters = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "lm.txt")
+        subprocess.run([os.path.join(ROOT, "oracle", "_ref", "dropin_driver"), "lmdump", str(n_cams), str(n_points),
+                        str(n_iters), path], check=True)
+        rows = {"C": [], "P": [], "O": [], "F": []}
+        for ln in open(path):
+            t = ln.split()
+            if t[0] in rows:
+                rows[t[0]].append([float(x) for x in t[1:]])
+    cams = np.array(rows["C"])
+    fin = rows["F"]
+    out = os.path.join(ROOT, "tests", "golden", "ba_lm_%d.npz" % n_cams)
+    np.savez_compressed(out, cams=cams[:, :6], intr=cams[:, 6:], points=np.array(rows["P"]), obs=np.array(rows["O"]),
+                        final_cams=np.array(fin[:n_cams]), final_points=np.array(fin[n_cams:]), max_iter=n_iters, threshold=0.01)
+    print(out, cams.shape, len(rows["P"]), len(rows["O"]))
+    sys.exit(0)
 n_poses = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 n_loops = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 with tempfile.TemporaryDirectory() as td:
