@@ -180,7 +180,8 @@ def se2_problem(n=3500, n_loops=2099, seed=1234, name="manhattan3500"):
     return Problem(name=name, dim=np.full(n, 3, dtype=np.int32), v0=v0, v1=v1, d0=3, d1=3, rd=3,
                    J0=np.ascontiguousarray(J0.transpose(0, 2, 1)).reshape(ne, 9),
                    J1=np.ascontiguousarray(J1.transpose(0, 2, 1)).reshape(ne, 9),
-                   Om=Om, r=r, unary_vertex=0, damping=0.0)
+                   Om=Om, r=r, unary_vertex=0, damping=0.0,
+                   geometry=dict(kind="se2", poses=np.concatenate([te, the[:, None]], axis=1), meas=zmeas))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -242,7 +243,24 @@ def se3_problem(rings=50, per_ring=50, seed=2500, name="sphere2500"):
     return Problem(name=name, dim=np.full(n, 6, dtype=np.int32), v0=v0, v1=v1, d0=6, d1=6, rd=6,
                    J0=np.ascontiguousarray(J0.transpose(0, 2, 1)).reshape(ne, 36),
                    J1=np.ascontiguousarray(J1.transpose(0, 2, 1)).reshape(ne, 36),
-                   Om=Om, r=r, unary_vertex=0, damping=0.0)
+                   Om=Om, r=r, unary_vertex=0, damping=0.0, geometry=dict(kind="se3", t=t, R=R, te=te, Re=Re, seed=seed))
+
+
+def pose_graph_states(prob):
+    """The same pose graph as states + measurements in the REFERENCE's parameterization, as input of
+    spp_se2_/se3_linearize_device: poses (n, 3) x y theta or (n, 6) [t | axis-angle] at the noisy estimate,
+    meas (ne, 3 or 6) = relative pose of the ground truth + sensor noise, v0 / v1 int32."""
+    g = prob.geometry
+    if g["kind"] == "se2":
+        return dict(dof=3, poses=g["poses"], meas=g["meas"], v0=prob.v0.astype(np.int32), v1=prob.v1.astype(np.int32))
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(g["seed"] + 1)
+    Rt, Re = Rotation.from_matrix(g["R"]), Rotation.from_matrix(g["Re"])   # from_matrix projects Re onto SO(3)
+    v0, v1 = prob.v0, prob.v1
+    zt = Rt[v0].inv().apply(g["t"][v1] - g["t"][v0]) + rng.normal(0, 0.05, size=(v0.size, 3))
+    zr = (Rt[v0].inv() * Rt[v1] * Rotation.from_rotvec(rng.normal(0, 0.01, size=(v0.size, 3)))).as_rotvec()
+    return dict(dof=6, poses=np.concatenate([g["te"], Re.as_rotvec()], axis=1), meas=np.concatenate([zt, zr], axis=1),
+                v0=v0.astype(np.int32), v1=v1.astype(np.int32))
 
 
 # ------------------------------------------------------------------------------------------------
