@@ -877,13 +877,18 @@ void front_fwd_kernel(const int32_t *__restrict__ level_fronts, const int64_t *_
 		}
 		__syncthreads();
 		if(wave == 0) {
+			// 64-step substitution by one wave: the reciprocals of the diagonal are taken once (one division
+			// per lane instead of one per step), and the running value travels through v_readlane with a
+			// compile-time lane (full unroll) instead of a ds_bpermute per step
 			double b = (lane < nbk) ? v[j0 + lane] : 0.0;
-			for(int i = 0; i < nbk; ++ i) {
-				const double yi = __shfl(b, i) / tri[i + i * (SB + 1)];
-				if(lane == i)
-					b = yi;
-				else if(lane > i && lane < nbk)
-					b -= tri[i + lane * (SB + 1)] * yi;
+			const double rinv = (lane < nbk) ? 1.0 / tri[lane + lane * (SB + 1)] : 0.0;
+#pragma unroll
+			for(int i = 0; i < SB; ++ i) {
+				if(i < nbk) { // wave-uniform
+					const double yi = readlane_f64(b, i) * readlane_f64(rinv, i);
+					const double tcol = tri[i + lane * (SB + 1)];
+					b = (lane == i) ? yi : ((lane > i && lane < nbk) ? b - tcol * yi : b);
+				}
 			}
 			if(lane < nbk) {
 				yb[lane] = b;
@@ -963,13 +968,15 @@ void front_bwd_kernel(const int32_t *__restrict__ level_fronts, const int64_t *_
 				for(int q = 0; q < FT / 64; ++ q)
 					t -= part[q][lane];
 			}
-			for(int i = nbk; i > 0;) {
+			const double rinv = (lane < nbk) ? 1.0 / tri[lane + lane * (SB + 1)] : 0.0;
+#pragma unroll
+			for(int i = SB; i > 0;) { // as in the forward kernel: reciprocals once, v_readlane with compile-time lanes
 				-- i;
-				const double xi = __shfl(t, i) / tri[i + i * (SB + 1)];
-				if(lane == i)
-					t = xi;
-				else if(lane < i)
-					t -= tri[lane + i * (SB + 1)] * xi;
+				if(i < nbk) { // wave-uniform
+					const double xi = readlane_f64(t, i) * readlane_f64(rinv, i);
+					const double tcol = tri[lane + i * (SB + 1)];
+					t = (lane == i) ? xi : ((lane < i) ? t - tcol * xi : t);
+				}
 			}
 			if(lane < nbk)
 				v[j0 + lane] = t;
