@@ -246,6 +246,48 @@ def se3_problem(rings=50, per_ring=50, seed=2500, name="sphere2500"):
                    Om=Om, r=r, unary_vertex=0, damping=0.0, geometry=dict(kind="se3", t=t, R=R, te=te, Re=Re, seed=seed))
 
 
+def landmark2d_problem(n_poses=80, n_lm=200, seed=32, interleave=False, name="lm2d_small"):
+    """2D poses (3) observing 2D point landmarks (2): ONE edge group (3, 2, 2) -- the pose-landmark edges of
+    victoria-park-style SLAM (CEdgePoseLandmark2D, include/slam/SE2_Types.h; range-bearing Jacobians of
+    C2DJacobians::Observation2D_RangeBearing, 2DSolverBase.h:420+). Every pose sees some landmarks and every
+    landmark is seen at least twice, so Lambda is positive definite with the unary factor on the first pose."""
+    rng = np.random.default_rng(seed)
+    nv = n_poses + n_lm
+    ids = rng.permutation(nv) if interleave else np.arange(nv)
+    pose_id, lm_id = ids[:n_poses], ids[n_poses:]
+    P = np.concatenate([rng.uniform(0, 30, size=(n_poses, 2)), rng.uniform(-np.pi, np.pi, size=(n_poses, 1))], axis=1)
+    Lm = rng.uniform(0, 30, size=(n_lm, 2))
+    from scipy.spatial import cKDTree
+    _, near = cKDTree(P[:, :2]).query(Lm, k=4)                    # each landmark: its 4 nearest poses
+    po = near.ravel()
+    lo = np.repeat(np.arange(n_lm), 4)
+    seen = np.zeros(n_poses, dtype=bool)
+    seen[po] = True
+    extra = np.flatnonzero(~seen)                                 # poses that saw nothing: give them their nearest landmark
+    if extra.size:
+        _, nl = cKDTree(Lm).query(P[extra, :2], k=2)
+        po = np.concatenate([po, np.repeat(extra, 2)])
+        lo = np.concatenate([lo, nl.ravel()])
+    ne = po.size
+    d = Lm[lo] - P[po, :2]
+    q = (d ** 2).sum(axis=1)
+    sq = np.sqrt(q)
+    J0 = np.zeros((ne, 2, 3))                                     # d(range, bearing) / d(x, y, theta)
+    J1 = np.zeros((ne, 2, 2))                                     # d(range, bearing) / d(lx, ly)
+    J0[:, 0, 0], J0[:, 0, 1] = -d[:, 0] / sq, -d[:, 1] / sq
+    J0[:, 1, 0], J0[:, 1, 1], J0[:, 1, 2] = d[:, 1] / q, -d[:, 0] / q, -1
+    J1[:, 0, 0], J1[:, 0, 1] = d[:, 0] / sq, d[:, 1] / sq
+    J1[:, 1, 0], J1[:, 1, 1] = -d[:, 1] / q, d[:, 0] / q
+    dim = np.empty(nv, dtype=np.int32)
+    dim[pose_id], dim[lm_id] = 3, 2
+    Om = np.tile(np.diag([100.0, 2500.0]).ravel(), (ne, 1))
+    r = rng.normal(0, 1, size=(ne, 2)) * np.array([0.1, 0.02])
+    return Problem(name=name, dim=dim, v0=pose_id[po], v1=lm_id[lo], d0=3, d1=2, rd=2,
+                   J0=np.ascontiguousarray(J0.transpose(0, 2, 1)).reshape(ne, 6),
+                   J1=np.ascontiguousarray(J1.transpose(0, 2, 1)).reshape(ne, 4),
+                   Om=Om, r=r, unary_vertex=int(pose_id[po[0]]), damping=1e-2)
+
+
 def pose_graph_states(prob):
     """The same pose graph as states + measurements in the REFERENCE's parameterization, as input of
     spp_se2_/se3_linearize_device: poses (n, 3) x y theta or (n, 6) [t | axis-angle] at the noisy estimate,
@@ -280,6 +322,8 @@ CONFIGS = {
     # a long camera trajectory: every point is seen from a narrow window of cameras, the reduced camera
     # system is banded (the shape of BASELINE config 5 at a size the CPU reference finishes in seconds)
     "ba_banded": lambda: ba_problem(600, 30000, 150000, 600, heavy_tail=False, spread=0.01, name="ba_banded"),
+    "lm2d_small": lambda: landmark2d_problem(80, 200, 32),
+    "lm2d_interleaved": lambda: landmark2d_problem(60, 150, 33, interleave=True, name="lm2d_interleaved"),
     "se2_small": lambda: se2_problem(300, 150, 12, name="se2_small"),
     "se3_small": lambda: se3_problem(8, 12, 13, name="se3_small"),
 }

@@ -27,7 +27,7 @@ def _assemble_gpu(ctx, prob, damping):
 
 
 @pytest.mark.parametrize("name", ["ba_tiny", "ba_small", "ba_interleaved", "ba_medium", "se2_small", "se3_small",
-                                  "manhattan3500", "sphere2500", "ladybug49"])
+                                  "manhattan3500", "sphere2500", "ladybug49", "lm2d_small", "lm2d_interleaved"])
 def test_assembly_matches_oracle(hip_ctx, name):
     prob = synth.make(name)
     lam_o, eta_o = orc.assemble(prob)

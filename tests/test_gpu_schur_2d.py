@@ -90,3 +90,28 @@ def test_pose_landmark_2d_schur_dense_and_sparse_reduced_system(n_poses, n_lm, i
             code, xr, _ = rs.solve(lam.vals, eta)
             assert code == 0 and _rel(xs[api.MODE_SCHUR], xr) < TOL, be
             rs.close()
+
+
+@pytest.mark.parametrize("name", ["lm2d_small", "lm2d_interleaved"])
+def test_range_bearing_group_assembled_and_solved_on_the_device(name):
+    """the (3, 2, 2) edge group end to end: device assembly (spp_assemble_device), guided Schur with 3-wide poses
+    and 2-wide landmarks, against the oracle's assembly + sparse block Cholesky"""
+    from slam_plus_plus_amd import synth
+    prob = synth.make(name)
+    lam_o, eta_o = orc.assemble(prob)
+    code, xo = orc.solve_blocky(lam_o, eta_o)
+    assert code == 0
+    ctx = api.Context(0)
+    st = ctx.assemble_analyze(prob.dim, prob.v0, prob.v1, 3, 2, 2, prob.unary_vertex)
+    arrs = [api.DeviceArray.from_host(ctx, a.ravel()) for a in (prob.J0, prob.J1, prob.Om, prob.r)]
+    dv, de = api.DeviceArray(ctx, st.nvals), api.DeviceArray(ctx, st.n)
+    ctx.assemble_device(*[a.ptr for a in arrs], prob.damping, dv.ptr, de.ptr)
+    assert np.abs(dv.download() - lam_o.vals).max() <= 1e-13 * np.abs(lam_o.vals).max()
+    for mode in (api.MODE_AUTO, api.MODE_SCHUR_SPARSE, api.MODE_SPARSE):
+        ctx.analyze(st, mode)
+        if mode == api.MODE_AUTO:
+            assert ctx.info("MODE") == api.MODE_SCHUR
+        dr = api.DeviceArray.from_host(ctx, de.download())
+        assert ctx.factor_solve_device(dv.ptr, dr.ptr) == 0
+        assert _rel(dr.download(), xo) < TOL
+    ctx.close()
