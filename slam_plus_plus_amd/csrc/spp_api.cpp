@@ -125,6 +125,11 @@ int spp_free_memory(spp_ctx *ctx)
 	ctx->dense.tinv.release();
 	ctx->dense.tinv_all.release();
 	ctx->dense.xtmp.release();
+	if(ctx->dense.gexec) {
+		(void)hipGraphExecDestroy(ctx->dense.gexec);
+		ctx->dense.gexec = nullptr;
+	}
+	ctx->dense.gseen = false;
 	ctx->geom_partial.release();
 	ctx->dense.flags.release();
 	ctx->dense.epoch = 0;

@@ -790,10 +790,60 @@ static void ensure_dense_work(spp_ctx *ctx, int64_t nblk)
 //          padded front height for a partial front factorization)
 //   ncols  columns carried along (rows + 1 with a rhs column)
 // Does not synchronize; failures are recorded in ctx->dense.info (first failing pivot + 1).
+static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, int64_t n, int64_t rows, int64_t ncols,
+	int64_t nsteps, bool has_rhs);
+
+// Optional (SPP_DENSE_GRAPH=1): the two-stream schedule of one factorization is captured into a hipGraph
+// the second time the same (buffer, shape) is factored and replayed afterwards -- the kernel arguments
+// are baked in, so the key is everything they depend on. Profiled solves (hipEvents between the
+// launches) always take the plain path.
 void dense_factor_steps(spp_ctx *ctx, double *d_A, int64_t ld, int64_t n, int64_t rows, int64_t ncols,
 	int64_t nsteps, bool has_rhs)
 {
 	ensure_dense_work(ctx, nsteps);
+	static int use_graph = -1;
+	if(use_graph < 0) {
+		const char *e = getenv("SPP_DENSE_GRAPH");
+		use_graph = e ? atoi(e) : 0;
+	}
+	DenseWork &dw = ctx->dense;
+	if(!use_graph || (ctx->flags & SPP_FLAG_PROFILE) || nsteps < 4) {
+		dense_factor_steps_enqueue(ctx, d_A, ld, n, rows, ncols, nsteps, has_rhs);
+		return;
+	}
+	const int64_t key[7] = {(int64_t)(uintptr_t)d_A, ld, n, rows, ncols, nsteps, has_rhs ? 1 : 0};
+	const bool same = !memcmp(key, dw.gkey, sizeof(key)) && dw.gstream == ctx->stream;
+	if(same && dw.gexec) {
+		SPP_HIP_CHECK(hipGraphLaunch(dw.gexec, ctx->stream));
+		return;
+	}
+	if(same && dw.gseen) { // second factorization of this buffer: every lazily initialized piece is warm
+		if(dw.gexec) {
+			(void)hipGraphExecDestroy(dw.gexec);
+			dw.gexec = nullptr;
+		}
+		hipGraph_t graph = nullptr;
+		SPP_HIP_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
+		dense_factor_steps_enqueue(ctx, d_A, ld, n, rows, ncols, nsteps, has_rhs);
+		SPP_HIP_CHECK(hipStreamEndCapture(ctx->stream, &graph));
+		SPP_HIP_CHECK(hipGraphInstantiate(&dw.gexec, graph, nullptr, nullptr, 0));
+		(void)hipGraphDestroy(graph);
+		SPP_HIP_CHECK(hipGraphLaunch(dw.gexec, ctx->stream));
+		return;
+	}
+	if(dw.gexec) {
+		(void)hipGraphExecDestroy(dw.gexec);
+		dw.gexec = nullptr;
+	}
+	memcpy(dw.gkey, key, sizeof(key));
+	dw.gstream = ctx->stream;
+	dw.gseen = true;
+	dense_factor_steps_enqueue(ctx, d_A, ld, n, rows, ncols, nsteps, has_rhs);
+}
+
+static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, int64_t n, int64_t rows, int64_t ncols,
+	int64_t nsteps, bool has_rhs)
+{
 	hipStream_t s = ctx->stream, s2 = ctx->dense.aux;
 	hipEvent_t evA = ctx->dense.ev[0], evB = ctx->dense.ev[1];
 	static int64_t trsm_shared_above = -1;

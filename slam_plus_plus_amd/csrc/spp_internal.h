@@ -130,7 +130,12 @@ struct DenseWork {
 	DevBuf<double> xtmp;           // solution of the backward substitution before it replaces y
 	DevBuf<int> flags;             // per block row: epoch of the solve that last published x_b (chain kernel)
 	int epoch = 0;
-	int *h_chain_err = nullptr;    // pinned: timeout flag of the chain kernel, valid after a stream sync
+	int *h_chain_err = nullptr;
+	// optional hipGraph of one factorization (SPP_DENSE_GRAPH): key = buffer + shape, see dense_factor_steps
+	hipGraphExec_t gexec = nullptr;
+	int64_t gkey[7] = {0, 0, 0, 0, 0, 0, 0};
+	hipStream_t gstream = nullptr;
+	bool gseen = false;    // pinned: timeout flag of the chain kernel, valid after a stream sync
 	hipStream_t aux = nullptr;     // lookahead stream: potrf_diag + trsm of the next panel
 	hipEvent_t ev[2] = {nullptr, nullptr};
 };
