@@ -51,6 +51,10 @@ def main():
     ap.add_argument("--workload", default="venice871")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-solves", type=int, default=2)
+    ap.add_argument("--cpu-backend", default="auto", choices=["auto", "schur", "cholmod", "csparse", "uberblock"],
+                    help="reference backend of the cpu_baseline leg. auto = the reference's FASTEST path for the workload "
+                         "(CLinearSolver_Schur + dense LLT for BA, UberBlock for pose graphs). north_star's CHOLMOD path "
+                         "takes ~150 s per Venice-shaped solve (DESIGN.md 5): run it explicitly with --cpu-backend cholmod --cpu-solves 1")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = every rank brings its own Venice-sized landmark set seen by the same 871 "
                          "cameras (per-GPU work fixed); strong = the one Venice problem sharded by landmarks")
@@ -325,7 +329,7 @@ def main():
             if orc.have_ref():
                 lam = st.with_vals(d_vals.download())
                 eta = d_eta.download()
-                backend = "schur" if schur else "uberblock"
+                backend = ("schur" if schur else "uberblock") if args.cpu_backend == "auto" else args.cpu_backend
                 rs = orc.RefSolver(backend, lam)
                 secs = []
                 for _ in range(args.cpu_solves):
@@ -335,7 +339,8 @@ def main():
                                        "sample": "%d full Lambda-solves of the same %s system by the reference's %s "
                                                  "(symbolic included in the first), best of %d: %.2f s" % (
                                                      args.cpu_solves, args.workload,
-                                                     "CLinearSolver_Schur + dense Eigen LLT" if backend == "schur" else "CLinearSolver_UberBlock",
+                                                     {"schur": "CLinearSolver_Schur + dense Eigen LLT", "uberblock": "CLinearSolver_UberBlock",
+                                                      "cholmod": "CLinearSolver_CholMod", "csparse": "CLinearSolver_CSparse"}[backend],
                                                      args.cpu_solves, min(secs)),
                                        "rel_diff_gpu_vs_reference": float(np.linalg.norm(x - xr) / np.linalg.norm(xr))}
             else:

@@ -353,6 +353,12 @@ bool dense_gemm_tn_sub(spp_ctx *ctx, int64_t m, int64_t n, int64_t k, const doub
 		launch_gemm<128, 128, 64, 32, 0, 2, 2, 32>(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc, upper_only);
 	else if(t128 >= 192 && cfg == 9)
 		launch_gemm<128, 128, 32, 32, 0, 1, 1>(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc, upper_only);
+	else if(t128 >= 192 && cfg == 12 && k % 32 == 0)
+		launch_gemm<128, 128, 32, 32, 0, 1, 1, 32>(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc, upper_only);
+	else if(t128 >= 192 && cfg == 13)
+		launch_gemm<128, 128, 32, 32, 0, 2, 1>(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc, upper_only);
+	else if(t128 >= 192 && cfg == 14 && k % 64 == 0)
+		launch_gemm<128, 128, 32, 32, 0, 1, 1, 64>(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc, upper_only);
 	else if(t128 >= 192 && cfg == 10)
 		launch_gemm<128, 64, 32, 32, 0, 1, 1>(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc, upper_only);
 	else if(t128 >= 192 && cfg == 11)
@@ -368,7 +374,7 @@ bool dense_gemm_tn_sub(spp_ctx *ctx, int64_t m, int64_t n, int64_t k, const doub
 	else
 		launch_gemm<64, 64, 32, 32, 0>(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc, upper_only);
 	SPP_HIP_CHECK(hipGetLastError());
-	return t128 >= 192; // true: the 128 x 128-tile kernel (the one the roofline is reported for) was launched
+	return t128 >= 192 && (cfg == 9 || cfg >= 12); // true: a 16-wave 128 x 128-tile kernel (the one the roofline is reported for) was launched
 }
 
 // --------------------------------------------------------------------------------------------------
