@@ -88,6 +88,10 @@ int spp_analyze(spp_ctx *ctx, int64_t nb, const int64_t *h_col_ptr, const int64_
 int spp_set_shard(spp_ctx *ctx, int rank, int world_size);
 
 /* facts about the analyzed system; unknown keys give SPP_E_BADARG */
+#define SPP_MODE_SCHUR_MIS 4  /* Schur complement over a maximal independent set of a ONE-width graph (3 or 6: pose
+                                 graphs): the general ordering of CSchurOrdering (src/slam/LinearSolver_Schur.cpp:690-769,
+                                 1235-1340); reduced system sparse, supernodal solve. Never chosen by AUTO */
+
 #define SPP_INFO_MODE           0  /* SPP_MODE_SPARSE, SPP_MODE_SCHUR or SPP_MODE_SCHUR_SPARSE actually chosen */
 #define SPP_INFO_N              1  /* scalar dimension */
 #define SPP_INFO_NNZB           2  /* stored blocks of Lambda (upper incl. diagonal) */

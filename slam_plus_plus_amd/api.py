@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspp_hip.so")
 
 SPP_OK, SPP_NOT_POSDEF = 0, 1
-MODE_AUTO, MODE_SPARSE, MODE_SCHUR, MODE_SCHUR_SPARSE = 0, 1, 2, 3
+MODE_AUTO, MODE_SPARSE, MODE_SCHUR, MODE_SCHUR_SPARSE, MODE_SCHUR_MIS = 0, 1, 2, 3, 4
 FLAG_PROFILE = 1
 INFO = dict(MODE=0, N=1, NNZB=2, NVALS=3, FACTOR_NNZ=4, FACTOR_FLOPS=5, N_REDUCED=6, N_POSES=7,
             N_LANDMARKS=8, SCHUR_PAIRS=9, N_OBS=10, SOLVE_BYTES=11, N_SUPERNODES=12, N_LEVELS=13, S_LD=14, S_NNZB=15)

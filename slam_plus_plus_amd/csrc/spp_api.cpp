@@ -261,14 +261,16 @@ int spp_analyze(spp_ctx *ctx, int64_t nb, const int64_t *col_ptr, const int64_t 
 			chosen = (n_red <= 16384) ? SPP_MODE_SCHUR : SPP_MODE_SCHUR_SPARSE;
 		}
 	}
-	SPP_REQUIRE(chosen == SPP_MODE_SCHUR || chosen == SPP_MODE_SPARSE || chosen == SPP_MODE_SCHUR_SPARSE, SPP_E_BADARG,
-		"unknown mode");
-	SPP_REQUIRE(chosen != SPP_MODE_SPARSE || ctx->shard_world == 1, SPP_E_UNSUPPORTED,
+	SPP_REQUIRE(chosen == SPP_MODE_SCHUR || chosen == SPP_MODE_SPARSE || chosen == SPP_MODE_SCHUR_SPARSE ||
+		chosen == SPP_MODE_SCHUR_MIS, SPP_E_BADARG, "unknown mode");
+	SPP_REQUIRE((chosen != SPP_MODE_SPARSE && chosen != SPP_MODE_SCHUR_MIS) || ctx->shard_world == 1, SPP_E_UNSUPPORTED,
 		"only the Schur modes shard (over landmarks); pose graphs run as replicas (DESIGN.md, multi-GPU)");
 	ctx->mode = -1;
-	if(chosen == SPP_MODE_SCHUR || chosen == SPP_MODE_SCHUR_SPARSE) {
-		const bool sparse_S = chosen == SPP_MODE_SCHUR_SPARSE;
-		build_schur_plan(ctx, sparse_S);
+	if(chosen == SPP_MODE_SCHUR || chosen == SPP_MODE_SCHUR_SPARSE || chosen == SPP_MODE_SCHUR_MIS) {
+		const bool mis = chosen == SPP_MODE_SCHUR_MIS;
+		const bool sparse_S = chosen != SPP_MODE_SCHUR; // the reduced system of a pose graph is sparse
+		build_schur_plan(ctx, sparse_S, mis);
+		ctx->schur.mis = mis;
 		ctx->order.clear();
 		if(sparse_S) {
 			sparse_analyze(ctx, ctx->schur.s_st); // leaves the elimination order of the reduced poses in ctx->order
@@ -283,7 +285,7 @@ int spp_analyze(spp_ctx *ctx, int64_t nb, const int64_t *col_ptr, const int64_t 
 		// landmarks are eliminated FIRST in elimination terms; the reference lists them last in its
 		// guided ordering (poses | landmarks), which is what order[] reports
 		for(int64_t j = 0; j < st.nb; ++ j)
-			if(st.dim[j] == ctx->schur.dl)
+			if(ctx->schur.is_lm[j])
 				ctx->order.push_back(j);
 	} else
 		sparse_analyze(ctx, ctx->st);
@@ -299,7 +301,8 @@ int spp_get_info(const spp_ctx *ctx, int what, int64_t *out)
 	if(ctx->mode < 0 && what != SPP_INFO_NNZB && what != SPP_INFO_NVALS && what != SPP_INFO_N)
 		return SPP_E_STATE;
 	switch(what) {
-	case SPP_INFO_MODE: *out = (ctx->mode == SPP_MODE_SCHUR && ctx->schur.sparse_S) ? SPP_MODE_SCHUR_SPARSE : ctx->mode; break;
+	case SPP_INFO_MODE: *out = (ctx->mode != SPP_MODE_SCHUR) ? ctx->mode : ctx->schur.mis ? SPP_MODE_SCHUR_MIS :
+		ctx->schur.sparse_S ? SPP_MODE_SCHUR_SPARSE : SPP_MODE_SCHUR; break;
 	case SPP_INFO_N: *out = ctx->st.n; break;
 	case SPP_INFO_NNZB: *out = ctx->st.nnzb; break;
 	case SPP_INFO_NVALS: *out = ctx->st.nvals; break;

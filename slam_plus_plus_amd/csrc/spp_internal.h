@@ -82,11 +82,13 @@ struct SchurPlan {
 	// reduced camera system kept SPARSE (block-CSC, dp x dp blocks) and solved by the supernodal path:
 	// S buffer = [ s_st.nvals block values | n_red reduced rhs ]
 	bool sparse_S = false;
+	bool mis = false;              // partition by a maximal independent set instead of by block width
 	Structure s_st;
 	DevBuf<int64_t> sblk_voff;     // [n_sblk] offset of the S block in the sparse value array
 	// host copies needed later
 	std::vector<int64_t> pose_block; // reduced pose index -> original block column
 	std::vector<int64_t> lm_block;   // owned landmark index -> original block column
+	std::vector<uint8_t> is_lm;      // per block column: eliminated by the Schur complement (any shard)
 	// device arrays
 	DevBuf<int32_t> lm_ptr;        // [nl+1] first obs of landmark
 	DevBuf<int64_t> lm_coff;       // [nl] offset of C block in vals
@@ -206,7 +208,7 @@ double ba_update(spp_ctx *ctx, int64_t nc, double *d_cams, const int64_t *d_cam_
 // ---- spp_symbolic.cpp ----
 void min_degree_order(int64_t nb, const int64_t *col_ptr, const int64_t *row_idx, std::vector<int64_t> &order);
 void nested_dissection_order(int64_t nb, const int64_t *col_ptr, const int64_t *row_idx, std::vector<int64_t> &order);
-void build_schur_plan(spp_ctx *ctx, bool sparse_S);
+void build_schur_plan(spp_ctx *ctx, bool sparse_S, bool mis = false);
 int64_t schur_buffer_doubles(const spp_ctx *ctx); // S | rhs buffer the Schur entry points work on
 bool schur_applicable(const Structure &st, int *dp, int *dl);
 

@@ -51,11 +51,48 @@ void cinv_kernel(int64_t nl, const int64_t *__restrict__ lm_coff, const double *
 		o[2] = COF_(0, 2) * id; o[5] = COF_(1, 2) * id; o[8] = COF_(2, 2) * id;
 #undef COF_
 #undef M_
-	} else { // DL == 2
+	} else if(DL == 2) {
 		const double det = m[0] * m[3] - m[2] * m[1];
 		const double id = -1.0 / det;
 		o[0] = m[3] * id; o[2] = -m[2] * id;
 		o[1] = -m[1] * id; o[3] = m[0] * id;
+	} else {
+		// 6 x 6 (MIS cut of a 3D pose graph): in-register Gauss-Jordan on [M | I] without pivoting (M is a
+		// diagonal block of an SPD matrix); Eigen's general inverse there is an LU with partial pivoting --
+		// same result to rounding on SPD blocks
+		double a[DL][DL], b[DL][DL];
+#pragma unroll
+		for(int i = 0; i < DL; ++ i)
+#pragma unroll
+			for(int j = 0; j < DL; ++ j) {
+				a[i][j] = m[i + DL * j];
+				b[i][j] = (i == j) ? 1.0 : 0.0;
+			}
+#pragma unroll
+		for(int k = 0; k < DL; ++ k) {
+			const double ip = 1.0 / a[k][k];
+#pragma unroll
+			for(int j = 0; j < DL; ++ j) {
+				a[k][j] *= ip;
+				b[k][j] *= ip;
+			}
+#pragma unroll
+			for(int i = 0; i < DL; ++ i) {
+				if(i == k)
+					continue;
+				const double f = a[i][k];
+#pragma unroll
+				for(int j = 0; j < DL; ++ j) {
+					a[i][j] -= f * a[k][j];
+					b[i][j] -= f * b[k][j];
+				}
+			}
+		}
+#pragma unroll
+		for(int i = 0; i < DL; ++ i)
+#pragma unroll
+			for(int j = 0; j < DL; ++ j)
+				o[i + DL * j] = -b[i][j];
 	}
 }
 
@@ -145,10 +182,12 @@ void s_accum_kernel(int64_t n_items, const int32_t *__restrict__ item_blk, const
 	int add_A, double *__restrict__ S, int64_t ld, const int64_t *__restrict__ sblk_voff, double *__restrict__ partial)
 {
 	constexpr int NE = DP * DP, BLK = DP * DL;
-	constexpr int PCS = (BLK + 1) / 2;          // 16-byte pieces per block (the last one half used when BLK is odd)
+	constexpr int PW = (BLK & 1) ? 1 : 2;       // doubles per fetched piece: 16-byte pieces need an even block (9-double
+	                                            // blocks of the 3 x 3 case are only 8-byte aligned: 8-byte pieces)
+	constexpr int PCS = BLK / PW;               // pieces per block
 	constexpr int PPI = 64 / PCS;               // blocks (pairs) fetched per wave instruction
 	constexpr int NG = (64 + PPI - 1) / PPI;    // instructions per operand and round
-	constexpr int ST = (2 * PCS) | 1;           // LDS stride of one block image in doubles (odd)
+	constexpr int ST = BLK | 1;                 // LDS stride of one block image in doubles (odd)
 	constexpr int RS = (NE + 1) / 2 + 1;        // row stride of the reduction image
 	static_assert(2 * 64 * ST >= 64 * RS, "the reduction image reuses the staging area");
 	__shared__ double lds[SACC_WAVES][2 * 64 * ST];
@@ -172,23 +211,37 @@ void s_accum_kernel(int64_t n_items, const int32_t *__restrict__ item_blk, const
 		const int32_t pa = (q < end) ? pair_a[q] : -1, pb = (q < end) ? pair_b[q] : -1;
 		// ---- cooperative fetch of up to 64 W and 64 U blocks into the LDS images
 		const int nround = (end - q0 < 64) ? end - q0 : 64;
-		double2 tw[NG], tu[NG];
+		constexpr int GC = (NG < 10) ? NG : 10; // groups in flight at a time (register budget of the 6 x 6 case)
 #pragma unroll
-		for(int g = 0; g < NG; ++ g) {
-			const int p = g * PPI + my_pair; // pair of this round served by this lane
-			const int32_t ia = __shfl(pa, p & 63), ib = __shfl(pb, p & 63);
-			const bool on = my_pair < PPI && p < nround;
-			tw[g] = on ? *(const double2*)(W + (int64_t)ia * BLK + 2 * my_piece) : make_double2(0, 0);
-			tu[g] = on ? *(const double2*)(Up + (int64_t)ib * BLK + 2 * my_piece) : make_double2(0, 0);
-		}
+		for(int g0 = 0; g0 < NG; g0 += GC) {
+			double tw[GC][PW], tu[GC][PW];
 #pragma unroll
-		for(int g = 0; g < NG; ++ g) {
-			const int p = g * PPI + my_pair;
-			if(my_pair < PPI && p < 64) {
-				sw[p * ST + 2 * my_piece] = tw[g].x;
-				sw[p * ST + 2 * my_piece + 1] = tw[g].y;
-				su[p * ST + 2 * my_piece] = tu[g].x;
-				su[p * ST + 2 * my_piece + 1] = tu[g].y;
+			for(int gg = 0; gg < GC; ++ gg) {
+				const int g = g0 + gg;
+				const int p = g * PPI + my_pair; // pair of this round served by this lane
+				const int32_t ia = __shfl(pa, p & 63), ib = __shfl(pb, p & 63);
+				const bool on = g < NG && my_pair < PPI && p < nround;
+				if(PW == 2) {
+					const double2 a2 = on ? *(const double2*)(W + (int64_t)ia * BLK + 2 * my_piece) : make_double2(0, 0);
+					const double2 b2 = on ? *(const double2*)(Up + (int64_t)ib * BLK + 2 * my_piece) : make_double2(0, 0);
+					tw[gg][0] = a2.x; tw[gg][PW - 1] = a2.y;
+					tu[gg][0] = b2.x; tu[gg][PW - 1] = b2.y;
+				} else {
+					tw[gg][0] = on ? W[(int64_t)ia * BLK + my_piece] : 0.0;
+					tu[gg][0] = on ? Up[(int64_t)ib * BLK + my_piece] : 0.0;
+				}
+			}
+#pragma unroll
+			for(int gg = 0; gg < GC; ++ gg) {
+				const int g = g0 + gg;
+				const int p = g * PPI + my_pair;
+				if(g < NG && my_pair < PPI && p < 64) {
+#pragma unroll
+					for(int t = 0; t < PW; ++ t) {
+						sw[p * ST + PW * my_piece + t] = tw[gg][t];
+						su[p * ST + PW * my_piece + t] = tu[gg][t];
+					}
+				}
 			}
 		}
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -498,17 +551,22 @@ void schur_pack(spp_ctx *ctx, double *S, double *packed, bool pack)
 
 void schur_form(spp_ctx *ctx, const double *d_vals, const double *d_rhs, double *d_S_rhs)
 {
-	if(ctx->schur.dp == 6)
-		schur_form_t<6, 3>(ctx, d_vals, d_rhs, d_S_rhs);
-	else
-		schur_form_t<3, 2>(ctx, d_vals, d_rhs, d_S_rhs);
+	const int dp = ctx->schur.dp, dl = ctx->schur.dl;
+	if(dp == 6 && dl == 3) schur_form_t<6, 3>(ctx, d_vals, d_rhs, d_S_rhs);
+	else if(dp == 3 && dl == 2) schur_form_t<3, 2>(ctx, d_vals, d_rhs, d_S_rhs);
+	else if(dp == 3 && dl == 3) schur_form_t<3, 3>(ctx, d_vals, d_rhs, d_S_rhs);
+	else if(dp == 6 && dl == 6) schur_form_t<6, 6>(ctx, d_vals, d_rhs, d_S_rhs);
+	else throw Error(SPP_E_UNSUPPORTED, "Schur kernels: block widths not instantiated");
 }
 
 int schur_finish(spp_ctx *ctx, const double *d_vals, double *d_S_rhs, double *d_rhs)
 {
-	if(ctx->schur.dp == 6)
-		return schur_finish_t<6, 3>(ctx, d_vals, d_S_rhs, d_rhs);
-	return schur_finish_t<3, 2>(ctx, d_vals, d_S_rhs, d_rhs);
+	const int dp = ctx->schur.dp, dl = ctx->schur.dl;
+	if(dp == 6 && dl == 3) return schur_finish_t<6, 3>(ctx, d_vals, d_S_rhs, d_rhs);
+	if(dp == 3 && dl == 2) return schur_finish_t<3, 2>(ctx, d_vals, d_S_rhs, d_rhs);
+	if(dp == 3 && dl == 3) return schur_finish_t<3, 3>(ctx, d_vals, d_S_rhs, d_rhs);
+	if(dp == 6 && dl == 6) return schur_finish_t<6, 6>(ctx, d_vals, d_S_rhs, d_rhs);
+	throw Error(SPP_E_UNSUPPORTED, "Schur kernels: block widths not instantiated");
 }
 
 } // namespace spp

@@ -24,10 +24,10 @@ void SchurPlan::release_all()
 	lm_ptr.release(); lm_coff.release(); lm_rbase.release(); obs_pose.release(); obs_lm.release();
 	obs_off.release(); pose_rbase.release(); cam_ptr.release(); cam_obs.release(); item_blk.release();
 	item_beg.release(); item_end.release(); obs_wpos.release(); xcd_beg.release(); item_slot.release(); sblk_i1.release(); sblk_i2.release(); sblk_aoff.release();
-	sblk_voff.release(); s_st = Structure(); sparse_S = false;
+	sblk_voff.release(); s_st = Structure(); sparse_S = false; mis = false;
 	pair_a.release(); pair_b.release(); multi_blk.release(); multi_ptr.release(); cinv.release();
 	W.release(); Up.release(); xw.release(); partial.release(); S.release();
-	pose_block.clear(); lm_block.clear();
+	pose_block.clear(); lm_block.clear(); is_lm.clear();
 }
 
 // Guided ordering is possible when there are exactly two block widths and the blocks of the
@@ -73,15 +73,66 @@ int64_t schur_buffer_doubles(const spp_ctx *ctx)
 	return sp.sparse_S ? sp.s_st.nvals + sp.n_red : sp.ld * sp.ld;
 }
 
-void build_schur_plan(spp_ctx *ctx, bool sparse_S)
+// Maximum-independent-set cut for graphs of ONE block width (the general ordering of the reference,
+// CSchurOrdering, src/slam/LinearSolver_Schur.cpp:690-769,1235-1340): vertices of the independent set play the
+// landmarks' role (their diagonal part C is block diagonal by construction), the rest forms the reduced
+// system. Greedy by ascending degree (ties by index): deterministic, maximal, not maximum.
+static bool mis_partition(const Structure &st, std::vector<uint8_t> &is_lm, int *d_out)
+{
+	const int d = st.dim[0];
+	for(int64_t j = 0; j < st.nb; ++ j)
+		if(st.dim[j] != d)
+			return false;
+	if(d != 3 && d != 6)
+		return false;
+	std::vector<std::vector<int32_t> > adj(st.nb);
+	for(int64_t j = 0; j < st.nb; ++ j)
+		for(int64_t p = st.col_ptr[j]; p < st.col_ptr[j + 1]; ++ p) {
+			const int64_t i = st.row_idx[p];
+			if(i != j) {
+				adj[i].push_back((int32_t)j);
+				adj[j].push_back((int32_t)i);
+			}
+		}
+	std::vector<int32_t> order(st.nb);
+	for(int64_t j = 0; j < st.nb; ++ j)
+		order[j] = (int32_t)j;
+	std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return adj[a].size() < adj[b].size(); });
+	is_lm.assign(st.nb, 0);
+	std::vector<uint8_t> blocked(st.nb, 0);
+	int64_t n_lm = 0;
+	for(int64_t q = 0; q < st.nb; ++ q) {
+		const int32_t v = order[q];
+		if(blocked[v])
+			continue;
+		is_lm[v] = 1;
+		++ n_lm;
+		for(size_t e = 0; e < adj[v].size(); ++ e)
+			blocked[adj[v][e]] = 1;
+	}
+	*d_out = d;
+	return n_lm > 0 && n_lm < st.nb;
+}
+
+void build_schur_plan(spp_ctx *ctx, bool sparse_S, bool mis)
 {
 	const Structure &st = ctx->st;
 	SchurPlan &sp = ctx->schur;
 	sp.release_all();
 	sp.sparse_S = sparse_S;
 	int dp, dl;
-	SPP_REQUIRE(schur_applicable(st, &dp, &dl), SPP_E_UNSUPPORTED,
-		"Schur mode needs exactly two block widths ({6,3} or {3,2}) and a block-diagonal landmark part");
+	std::vector<uint8_t> is_lm;
+	if(mis) {
+		SPP_REQUIRE(mis_partition(st, is_lm, &dp), SPP_E_UNSUPPORTED,
+			"MIS Schur mode needs a graph of one block width (3 or 6) with at least one edge");
+		dl = dp;
+	} else {
+		SPP_REQUIRE(schur_applicable(st, &dp, &dl), SPP_E_UNSUPPORTED,
+			"Schur mode needs exactly two block widths ({6,3} or {3,2}) and a block-diagonal landmark part");
+		is_lm.assign(st.nb, 0);
+		for(int64_t j = 0; j < st.nb; ++ j)
+			is_lm[j] = st.dim[j] == dl;
+	}
 	sp.dp = dp;
 	sp.dl = dl;
 	hipStream_t s = ctx->stream;
@@ -90,7 +141,7 @@ void build_schur_plan(spp_ctx *ctx, bool sparse_S)
 	std::vector<int32_t> pose_of(st.nb, -1), lm_of(st.nb, -1);
 	int64_t nc = 0, nl_total = 0, nl = 0;
 	for(int64_t j = 0; j < st.nb; ++ j) {
-		if(st.dim[j] == dp) {
+		if(!is_lm[j]) {
 			pose_of[j] = (int32_t)nc ++;
 			sp.pose_block.push_back(j);
 		} else {
@@ -102,6 +153,7 @@ void build_schur_plan(spp_ctx *ctx, bool sparse_S)
 			++ nl_total;
 		}
 	}
+	sp.is_lm = is_lm;
 	sp.nc = nc;
 	sp.nl = nl;
 	sp.nl_total = nl_total;
@@ -120,7 +172,7 @@ void build_schur_plan(spp_ctx *ctx, bool sparse_S)
 	for(int64_t j = 0; j < st.nb; ++ j) {
 		for(int64_t p = st.col_ptr[j]; p < st.col_ptr[j + 1]; ++ p) {
 			const int64_t i = st.row_idx[p]; // i <= j
-			const bool pi = st.dim[i] == dp, pj = st.dim[j] == dp;
+			const bool pi = !is_lm[i], pj = !is_lm[j];
 			if(pi && pj)
 				ablk.push_back({pose_of[i], pose_of[j], st.blk_off[p]}); // i <= j and stable partition keep i1 <= i2
 			else if(!pi && !pj) {
@@ -145,13 +197,13 @@ void build_schur_plan(spp_ctx *ctx, bool sparse_S)
 		std::vector<int64_t> lm_gidx(st.nb, -1);
 		int64_t g = 0;
 		for(int64_t j = 0; j < st.nb; ++ j)
-			if(st.dim[j] != dp)
+			if(is_lm[j])
 				lm_gidx[j] = g ++;
 		std::vector<std::vector<int32_t> > poses_of(g);
 		for(int64_t j = 0; j < st.nb; ++ j)
 			for(int64_t p = st.col_ptr[j]; p < st.col_ptr[j + 1]; ++ p) {
 				const int64_t i = st.row_idx[p];
-				const bool pi = st.dim[i] == dp, pj = st.dim[j] == dp;
+				const bool pi = !is_lm[i], pj = !is_lm[j];
 				if(pi && !pj && lm_of[j] < 0)
 					poses_of[lm_gidx[j]].push_back(pose_of[i]);
 				else if(!pi && pj && lm_of[i] < 0)
