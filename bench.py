@@ -307,11 +307,12 @@ def main():
                 traffic = json.load(open(pmc)).get(args.workload, {}).get("bytes_per_launch")
             except Exception:
                 traffic = None
-        out["roofline"] = {"bound": "mfma", "kernel": "spp::gemm_tn_kernel<128, 128, 32, 32, 0, 1, 1, 16> (MFMA f64 16x16x4 trailing update of the dense factor, 128x128 tiles)",
+        out["roofline"] = {"bound": "mfma", "kernel": "spp::gemm_tn_mixed_kernel (MFMA f64 16x16x4 trailing update of the dense factor: 128x128 tiles, the tail of every launch cut into 64x64 quarters)",
                            "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
                            "launches_per_solve": int(dom_n), "avg_launch_ms": dom_ms / dom_n,
                            "flops_per_launch": dom_flops / dom_n,
+                           "standalone_update_tflops": (lambda m: (128.0 * m * (m + 1) + 256.0 * m) / ctx.microbench_update(m, 20) * 1e-9)(5120),
                            "measured_mfma_f64_peak": ctx.microbench_mfma_f64(4000),
                            "measured_copy_gbs": ctx.microbench_copy(1 << 30, 10),
                            "measured_ctile_rw_gbs": ctx.microbench_ctile(8192, 5)}

@@ -260,6 +260,10 @@ int spp_microbench_mfma_f64(spp_ctx *ctx, int iters, double *tflops);
 /* read-negate-write of an n x n fp64 matrix (n % 128 == 0) in the trailing-update kernel's C-tile lane
    pattern; a known byte count (2 * 8 * n * n per launch) to calibrate the PMC traffic counters with */
 int spp_microbench_ctile(spp_ctx *ctx, int n, int iters, double *gb_per_s);
+/* the bulk trailing update of ONE dense factorization step, stand-alone: an m x (m + 1) trailing matrix (upper
+ * tiles) receives a rank-128 update `iters` times back to back; *ms_per_launch = hipEvent time per launch.
+ * Useful flops per launch = 128 m (m + 1) + 256 m (what bench.py's roofline counts for the same launch). */
+int spp_microbench_update(spp_ctx *ctx, int64_t m, int iters, double *ms_per_launch);
 
 /* direct access to the dense kernels for unit tests (device pointers; A is n x n col-major, ld) */
 int spp_dense_potrf_upper(spp_ctx *ctx, double *d_A, int64_t n, int64_t ld);

@@ -32,7 +32,7 @@ EXPORTS = [
     "spp_schur_packed_size", "spp_schur_pack", "spp_schur_unpack",
     "spp_assemble_analyze", "spp_assemble_get_structure", "spp_assemble_device", "spp_device_malloc",
     "spp_device_free", "spp_memcpy_h2d", "spp_memcpy_d2h", "spp_memcpy_d2d", "spp_get_phase_ms", "spp_get_dominant_kernel",
-    "spp_microbench_copy", "spp_microbench_mfma_f64", "spp_microbench_ctile", "spp_block_ordering", "spp_set_profiling", "spp_se2_linearize_device", "spp_se2_update_device", "spp_ba_linearize_device", "spp_ba_update_device", "spp_se3_linearize_device", "spp_se3_update_device", "spp_edge_chi2_device", "spp_edge_hessian_maxdiag_device",
+    "spp_microbench_copy", "spp_microbench_mfma_f64", "spp_microbench_ctile", "spp_microbench_update", "spp_block_ordering", "spp_set_profiling", "spp_se2_linearize_device", "spp_se2_update_device", "spp_ba_linearize_device", "spp_ba_update_device", "spp_se3_linearize_device", "spp_se3_update_device", "spp_edge_chi2_device", "spp_edge_hessian_maxdiag_device",
     "spp_lm_gain_denominator_device", "spp_dense_potrf_upper", "spp_dense_posv",
     "spp_dense_gemm_tn_sub", "spp_version",
 ]
@@ -88,6 +88,7 @@ def load_library():
         "spp_microbench_copy": (cint, [vp, ctypes.c_size_t, cint, _c_f64p]),
         "spp_microbench_mfma_f64": (cint, [vp, cint, _c_f64p]),
         "spp_microbench_ctile": (cint, [vp, cint, cint, _c_f64p]),
+        "spp_microbench_update": (cint, [vp, ctypes.c_int64, cint, _c_f64p]),
         "spp_block_ordering": (cint, [ctypes.c_int64, vp, vp, cint, vp]),
         "spp_set_profiling": (cint, [vp, cint]),
         "spp_se2_linearize_device": (cint, [vp, ctypes.c_int64, vp, vp, vp, vp, vp, vp, vp]),
@@ -340,6 +341,12 @@ class Context:
     def microbench_ctile(self, n=8192, iters=10):
         out = ctypes.c_double()
         self._check(self.lib.spp_microbench_ctile(self.h, n, iters, ctypes.byref(out)))
+        return out.value
+
+    def microbench_update(self, m=5120, iters=20):
+        """ms per launch of the stand-alone bulk trailing update of an m x (m + 1) trailing matrix"""
+        out = ctypes.c_double()
+        self._check(self.lib.spp_microbench_update(self.h, m, iters, ctypes.byref(out)))
         return out.value
 
     def microbench_mfma_f64(self, iters=4000):

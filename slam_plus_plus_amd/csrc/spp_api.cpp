@@ -749,6 +749,17 @@ int spp_microbench_ctile(spp_ctx *ctx, int n, int iters, double *gb_per_s)
 	SPP_CATCH(ctx)
 }
 
+int spp_microbench_update(spp_ctx *ctx, int64_t m, int iters, double *ms_per_launch)
+{
+	if(!ctx || !ms_per_launch || m < 128 || iters < 1)
+		return SPP_E_BADARG;
+	SPP_TRY(ctx)
+	SPP_HIP_CHECK(hipSetDevice(ctx->device));
+	*ms_per_launch = microbench_update(ctx, m, iters);
+	return SPP_OK;
+	SPP_CATCH(ctx)
+}
+
 int spp_microbench_mfma_f64(spp_ctx *ctx, int iters, double *tflops)
 {
 	if(!ctx || !tflops)

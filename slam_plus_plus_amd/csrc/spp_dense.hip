@@ -32,6 +32,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <vector>
 
 namespace spp {
 
@@ -46,10 +47,10 @@ constexpr int LDS_STRIDE = 18;   // doubles per tile column in LDS: conflict-fre
 // MINW = waves per SIMD the register allocator must leave room for (2nd argument of
 // __launch_bounds__): 2 for the 512-thread configuration = one workgroup per CU and a 256-VGPR budget
 // (at the default budget of 128 the staging registers were spilled to scratch inside the k-loop)
-template <int BM, int BN, int WM, int WN, int MODE, int DEPTH = 2, int MINW = 1, int BKT = 16>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_waves_per_eu(MINW == 2 ? 2 : 1, MINW == 2 ? 2 : 8)))
-void gemm_tn_kernel(int64_t M, int64_t N, int K, const double *__restrict__ A, int64_t lda,
-	const double *B, int64_t ldb, double *C, int64_t ldc, int upper_only)
+// one BM x BN tile of C at (m0, n0) by the whole workgroup (the body shared by the kernels below)
+template <int BM, int BN, int WM, int WN, int MODE, int DEPTH, int BKT>
+__device__ __forceinline__ void gemm_tn_tile(const int64_t m0, const int64_t n0, int64_t M, int64_t N, int K,
+	const double *__restrict__ A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, double *gemm_lds)
 {
 	constexpr int NWM = BM / WM, NWN = BN / WN, NT = NWM * NWN * 64;
 	constexpr int TA = WM / 16, TB = WN / 16;       // MFMA tiles per wave
@@ -57,16 +58,13 @@ void gemm_tn_kernel(int64_t M, int64_t N, int K, const double *__restrict__ A, i
 	constexpr int PA = (BM * PPC) / NT, PB = (BN * PPC) / NT; // pieces per thread per slab
 	static_assert((BM * PPC) % NT == 0 && (BN * PPC) % NT == 0, "tile/threads mismatch");
 
-	const int64_t m0 = (int64_t)blockIdx.x * BM, n0 = (int64_t)blockIdx.y * BN;
-	if(upper_only && m0 >= n0 + BN)
-		return; // tile strictly below the diagonal
-
-	extern __shared__ double gemm_lds[];
 	double *As = gemm_lds, *Bs = gemm_lds + BM * LSTR;
 
-	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	const int wm = (wave % NWM) * WM, wn = (wave / NWM) * WN;
+	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int wm = (wave % NWM) * WM, wn = (wave / NWM) * WN; // wave-uniform (scalar registers)
 	const int l15 = lane & 15, l4 = lane >> 4;
+	// C(m, n) = (uniform tile corner) + lane part: one 32-bit offset register serves all 16 accesses
+	const uint32_t c_lane = (uint32_t)(l15 + l4 * ldc);
 
 	v4f64 acc[TB][TA];
 	// MODE 0: the old C values are fetched up front (their latency hides under the whole k-loop) and
@@ -77,12 +75,12 @@ void gemm_tn_kernel(int64_t M, int64_t N, int K, const double *__restrict__ A, i
 		for(int a = 0; a < TA; ++ a) {
 			acc[b][a] = (v4f64){0, 0, 0, 0};
 			if(MODE == 0) {
-				const int64_t m = m0 + wm + a * 16 + l15;
+				const int64_t mu = m0 + wm + a * 16, nu = n0 + wn + b * 16;
+				const double *Cu = C + mu + nu * ldc;
 #pragma unroll
 				for(int r = 0; r < 4; ++ r) {
-					const int64_t n = n0 + wn + b * 16 + l4 + 4 * r;
-					if(m < M && n < N)
-						acc[b][a][r] = -C[m + n * ldc];
+					if(mu + l15 < M && nu + l4 + 4 * r < N)
+						acc[b][a][r] = -(Cu + (int64_t)(4 * r) * ldc)[c_lane];
 				}
 			}
 		}
@@ -169,14 +167,95 @@ void gemm_tn_kernel(int64_t M, int64_t N, int K, const double *__restrict__ A, i
 	for(int b = 0; b < TB; ++ b)
 #pragma unroll
 		for(int a = 0; a < TA; ++ a) {
-			const int64_t m = m0 + wm + a * 16 + l15;
+			const int64_t mu = m0 + wm + a * 16, nu = n0 + wn + b * 16;
+			double *Cu = C + mu + nu * ldc;
 #pragma unroll
 			for(int r = 0; r < 4; ++ r) {
-				const int64_t n = n0 + wn + b * 16 + l4 + 4 * r;
-				if(m < M && n < N)
-					C[m + n * ldc] = (MODE == 0) ? -acc[b][a][r] : acc[b][a][r];
+				if(mu + l15 < M && nu + l4 + 4 * r < N)
+					(Cu + (int64_t)(4 * r) * ldc)[c_lane] = (MODE == 0) ? -acc[b][a][r] : acc[b][a][r];
 			}
 		}
+}
+
+template <int BM, int BN, int WM, int WN, int MODE, int DEPTH = 2, int MINW = 1, int BKT = 16>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_waves_per_eu(MINW == 2 ? 2 : 1, MINW == 2 ? 2 : 8)))
+void gemm_tn_kernel(int64_t M, int64_t N, int K, const double *__restrict__ A, int64_t lda,
+	const double *B, int64_t ldb, double *C, int64_t ldc, int upper_only)
+{
+	const int64_t m0 = (int64_t)blockIdx.x * BM, n0 = (int64_t)blockIdx.y * BN;
+	if(upper_only && m0 >= n0 + BN)
+		return; // tile strictly below the diagonal
+	extern __shared__ double gemm_lds[];
+	gemm_tn_tile<BM, BN, WM, WN, MODE, DEPTH, BKT>(m0, n0, M, N, K, A, lda, B, ldb, C, ldc, gemm_lds);
+}
+
+// --------------------------------------------------------------------------------------------------
+// Trailing update with a fine-grained tail. A 128 x 128 tile occupies its workgroup for ~55 us and the
+// chip holds 512 of them: 528 tiles took as long as 1024. Here the upper tiles are enumerated in ONE
+// dimension (tile columns, rows ascending); the first n128 are processed whole, every remaining tile is
+// cut into four 64 x 64 quarters, each by its own workgroup (16 waves, one MFMA tile per wave): the
+// dispatcher hands out the long items first and levels the end of the launch with the short ones.
+//   nt = tile rows (M), ntc = tile columns (N >= M); tile t -> (i, j), i <= min(j, nt - 1)
+// --------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void upper_tile_of(int64_t t, int nt, int &ti, int &tj)
+{
+	const int64_t tri = (int64_t)nt * (nt + 1) / 2;
+	if(t >= tri) { // rectangular part right of the square (right-hand side columns)
+		const int64_t q = t - tri;
+		tj = nt + (int)(q / nt);
+		ti = (int)(q % nt);
+		return;
+	}
+	int j = (int)((__dsqrt_rn(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+	while((int64_t)j * (j + 1) / 2 > t) -- j;
+	while((int64_t)(j + 1) * (j + 2) / 2 <= t) ++ j;
+	tj = j;
+	ti = (int)(t - (int64_t)j * (j + 1) / 2);
+}
+
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void gemm_tn_mixed_kernel(int64_t M, int64_t N, int K, const double *__restrict__ A, int64_t lda,
+	const double *B, int64_t ldb, double *C, int64_t ldc, int nt, int64_t n128)
+{
+	extern __shared__ double gemm_lds[];
+	const int64_t b = blockIdx.x;
+	int ti, tj;
+	if(b < n128) {
+		upper_tile_of(b, nt, ti, tj);
+		gemm_tn_tile<128, 128, 32, 32, 0, 1, 16>((int64_t)ti * 128, (int64_t)tj * 128, M, N, K, A, lda, B, ldb, C, ldc, gemm_lds);
+	} else {
+		const int64_t q = b - n128;
+		upper_tile_of(n128 + (q >> 2), nt, ti, tj);
+		const int64_t m0 = (int64_t)ti * 128 + (q & 1) * 64, n0 = (int64_t)tj * 128 + ((q >> 1) & 1) * 64;
+		if(m0 >= n0 + 64 || m0 >= M || n0 >= N)
+			return; // quarter strictly below the diagonal or outside the matrix
+		gemm_tn_tile<64, 64, 16, 16, 0, 1, 32>(m0, n0, M, N, K, A, lda, B, ldb, C, ldc, gemm_lds);
+	}
+}
+
+// returns false when the shape is not worth it (the caller falls back to the plain kernels)
+static bool launch_gemm_mixed(hipStream_t s, int64_t M, int64_t N, int K, const double *A, int64_t lda,
+	const double *B, int64_t ldb, double *C, int64_t ldc)
+{
+	static int64_t slots = -1, whole_below = -1;
+	if(slots < 0) {
+		const char *e = getenv("SPP_MIX_SLOTS"); // concurrently resident 128 x 128 workgroups (2 per CU)
+		slots = e ? atol(e) : 512;
+		e = getenv("SPP_MIX_WHOLE_BELOW"); // launches with fewer tiles than this are not cut at all
+		whole_below = e ? atol(e) : 0;
+	}
+	if(slots == 0 || K % 32 != 0 || N < M)
+		return false;
+	const int64_t nt = (M + 127) / 128, ntc = (N + 127) / 128;
+	const int64_t T = nt * (nt + 1) / 2 + (ntc - nt) * nt;
+	int64_t n128 = (T / slots) * slots;
+	if(T < whole_below)
+		n128 = T;
+	const int64_t grid = n128 + 4 * (T - n128);
+	const size_t lds = (size_t)(128 + 128) * 18 * sizeof(double); // >= (64 + 64) * 34 doubles of the quarter path
+	hipLaunchKernelGGL(gemm_tn_mixed_kernel, dim3((unsigned)grid), dim3(1024), lds, s,
+		M, N, K, A, lda, B, ldb, C, ldc, (int)nt, n128);
+	return true;
 }
 
 template <int BM, int BN, int WM, int WN, int MODE, int DEPTH = 2, int MINW = 1, int BKT = 16>
@@ -337,9 +416,12 @@ bool dense_gemm_tn_sub(spp_ctx *ctx, int64_t m, int64_t n, int64_t k, const doub
 	if(upper_only)
 		t128 = t128 / 2 + 1;
 	static int cfg = -1;
+	static int64_t mix_min_tiles = 192;
 	if(cfg < 0) {
 		const char *e = getenv("SPP_GEMM_CFG");
 		cfg = e ? atoi(e) : 9;
+		e = getenv("SPP_MIX_MIN_TILES"); // the mixed-granularity kernel takes every upper update of at least this many 128 x 128 tiles
+		mix_min_tiles = e ? atol(e) : 50;
 	}
 	if(t128 >= 192 && cfg == 1)
 		launch_gemm<128, 128, 64, 32, 0, 1>(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc, upper_only);
@@ -351,8 +433,12 @@ bool dense_gemm_tn_sub(spp_ctx *ctx, int64_t m, int64_t n, int64_t k, const doub
 		launch_gemm<128, 128, 64, 32, 0, 1, 2, 32>(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc, upper_only);
 	else if(t128 >= 192 && cfg == 7 && k % 32 == 0)
 		launch_gemm<128, 128, 64, 32, 0, 2, 2, 32>(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc, upper_only);
-	else if(t128 >= 192 && cfg == 9)
-		launch_gemm<128, 128, 32, 32, 0, 1, 1>(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc, upper_only);
+	else if(t128 >= mix_min_tiles && cfg == 9 && upper_only && launch_gemm_mixed(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc))
+		return true;
+	else if(t128 >= 192 && cfg == 9) {
+		if(!upper_only || !launch_gemm_mixed(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc))
+			launch_gemm<128, 128, 32, 32, 0, 1, 1>(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc, upper_only);
+	}
 	else if(t128 >= 192 && cfg == 12 && k % 32 == 0)
 		launch_gemm<128, 128, 32, 32, 0, 1, 1, 32>(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc, upper_only);
 	else if(t128 >= 192 && cfg == 13)
@@ -769,6 +855,19 @@ static void ensure_dense_work(spp_ctx *ctx, int64_t nblk)
 		int prio_lo = 0, prio_hi = 0;
 		SPP_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
 		const char *e = getenv("SPP_AUX_PRIO");
+		// SPP_AUX_RESERVE_CUS = n: the bulk stream is created with a CU mask that leaves the first n CUs to the
+		// chain (experiment: potrf_diag then always finds an idle CU)
+		const char *r = getenv("SPP_AUX_RESERVE_CUS");
+		const int reserve = r ? atoi(r) : 32;
+		if(reserve > 0) {
+			hipDeviceProp_t prop;
+			SPP_HIP_CHECK(hipGetDeviceProperties(&prop, ctx->device));
+			const int ncu = prop.multiProcessorCount, nw = (ncu + 31) / 32;
+			std::vector<uint32_t> mask((size_t)nw, 0u);
+			for(int c = reserve; c < ncu; ++ c)
+				mask[(size_t)c / 32] |= 1u << (c % 32);
+			SPP_HIP_CHECK(hipExtStreamCreateWithCUMask(&ctx->dense.aux, (uint32_t)nw, mask.data()));
+		} else
 		SPP_HIP_CHECK(hipStreamCreateWithPriority(&ctx->dense.aux, hipStreamNonBlocking,
 			(e && !strcmp(e, "hi")) ? prio_hi : prio_lo));
 		SPP_HIP_CHECK(hipEventCreateWithFlags(&ctx->dense.ev[0], hipEventDisableTiming));
@@ -883,13 +982,29 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 	// the HBM ridge: 8 flop/B). Within a pair the chain stream does
 	//   tile row k+1 <- panel k | potrf(k+1), panel k+1 | tile row k+2 <- panels k, k+1
 	// and the bulk stream updates everything below tile row k+2 with both panels.
+	static int tilerow_tile = -1;
+	static int64_t tilerow_slab_above = 0;
+	if(tilerow_tile < 0) {
+		const char *e = getenv("SPP_TILEROW_TILE");
+		tilerow_tile = e ? atoi(e) : 32;
+		e = getenv("SPP_TILEROW_SLAB_ABOVE");
+		tilerow_slab_above = e ? atol(e) : (int64_t(1) << 40);
+	}
 	auto tile_row = [&](int64_t r0, int64_t kp0, int npan) { // rows [r0, r0+128) x cols [r0, ncols) -= P^T P, panels at kp0
 		const int64_t m = std::min<int64_t>(NB, rows - r0);
 		if(m <= 0 || r0 >= ncols)
 			return;
 		for(int q = 0; q < npan; ++ q) {
 			const double *P = d_A + (kp0 + q * NB) + r0 * ld;
-			launch_gemm_staged<64, 64, 32, 32, 0>(s, m, ncols - r0, NB, P, ld, P, ld, d_A + r0 + r0 * ld, ld, true);
+			// Under a running bulk update every wave slot of the chip is taken and a tile-row workgroup only
+			// starts where a bulk workgroup has just left: the fully staged kernel (66 KB of LDS) fits once
+			// into such a hole, the slab-pipelined one (18 KB, one wave per SIMD) four times.
+			if(rows - r0 > tilerow_slab_above)
+				launch_gemm<64, 64, 32, 32, 0, 1>(s, m, ncols - r0, NB, P, ld, P, ld, d_A + r0 + r0 * ld, ld, true);
+			else if(tilerow_tile == 32)
+				launch_gemm_staged<32, 32, 16, 16, 0>(s, m, ncols - r0, NB, P, ld, P, ld, d_A + r0 + r0 * ld, ld, true);
+			else
+				launch_gemm_staged<64, 64, 32, 32, 0>(s, m, ncols - r0, NB, P, ld, P, ld, d_A + r0 + r0 * ld, ld, true);
 		}
 	};
 	potrf_and_panel(s, 0);
@@ -905,19 +1020,60 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 		pair_above = e ? atol(e) : (int64_t(1) << 40); // pair while the trailing matrix is LARGER than this (bulk-bound phase)
 	}
 	static int eva_early = -1;
+	static int64_t early_above = 0;
 	if(eva_early < 0) {
 		const char *e = getenv("SPP_EVA_EARLY");
 		eva_early = e ? atoi(e) : 1;
+		e = getenv("SPP_EARLY_ABOVE"); // the bulk update is handed over before the tile row only while it bounds the step
+		early_above = e ? atol(e) : 0;
+	}
+	// Once the trailing matrix is small the whole update is shorter than a cross-stream hand-off plus the
+	// tile row (two events cost ~12 us per step): the step then runs on the chain stream alone,
+	//   potrf(k), panel(k), ONE launch updating every trailing tile, potrf(k+1) ...
+	// SPP_SINGLE_BELOW = trailing rows at or below which a step is single-stream.
+	static int64_t single_below = -1;
+	static int single_tile = 64;
+	static int64_t single_mixed_above = 1280;
+	if(single_below < 0) {
+		const char *e = getenv("SPP_SINGLE_BELOW");
+		single_below = e ? atol(e) : 2560;
+		e = getenv("SPP_SINGLE_TILE");
+		single_tile = e ? atoi(e) : 32;
+		e = getenv("SPP_SINGLE_MIXED_ABOVE");
+		single_mixed_above = e ? atol(e) : 1280;
 	}
 	for(int64_t k = 0; k < nsteps;) {
 		const int64_t k0 = k * NB, c1 = k0 + NB, c2 = c1 + NB, c3 = c2 + NB;
 		const int npan = ((rows - c1 < pair_below || rows - c1 > pair_above) && k + 1 < nsteps) ? 2 : 1;
 		if(c1 >= ncols || rows - c1 <= 0)
 			break;
+		if(rows - c1 <= single_below) {
+			if(bulk_pending) {
+				SPP_HIP_CHECK(hipStreamWaitEvent(s, evB, 0));
+				bulk_pending = false;
+			}
+			const double *P = d_A + k0 + c1 * ld;
+			if(rows - c1 >= single_mixed_above) { // the fine-grained MFMA kernel wins from ~10 tile rows on
+				dom_begin(ctx);
+				const bool big = dense_gemm_tn_sub(ctx, rows - c1, ncols - c1, NB, P, ld, P, ld, d_A + c1 + c1 * ld, ld, true);
+				const double mr = (double)(rows - c1);
+				if(big)
+					dom_end(ctx, 2.0 * NB * (0.5 * mr * (mr + 1.0) + mr * (double)(ncols - rows)));
+			} else if(single_tile == 32)
+				launch_gemm_staged<32, 32, 16, 16, 0>(s, rows - c1, ncols - c1, NB, P, ld, P, ld, d_A + c1 + c1 * ld, ld, true);
+			else if(single_tile == 48)
+				launch_gemm_staged<64, 32, 32, 16, 0>(s, rows - c1, ncols - c1, NB, P, ld, P, ld, d_A + c1 + c1 * ld, ld, true);
+			else
+				launch_gemm_staged<64, 64, 32, 32, 0>(s, rows - c1, ncols - c1, NB, P, ld, P, ld, d_A + c1 + c1 * ld, ld, true);
+			if(k + 1 < nsteps)
+				potrf_and_panel(s, k + 1);
+			++ k;
+			continue;
+		}
 		// A single-panel bulk update needs only row panel k (complete at this point of the chain stream)
 		// and writes rows >= c2, disjoint from the tile row the chain touches next: hand it to the bulk
 		// stream BEFORE the tile row, so that consecutive bulk updates run back to back.
-		const bool early = (npan == 1) && eva_early;
+		const bool early = (npan == 1) && eva_early && rows - c1 > early_above;
 		if(early)
 			SPP_HIP_CHECK(hipEventRecord(evA, s));
 		// the bulk update of the previous pair touched every row >= c1 (evB still names that update:
@@ -1167,6 +1323,33 @@ double microbench_mfma_f64(spp_ctx *ctx, int iters)
 	// per wave: iters * 8 MFMAs of 16*16*4*2 flops
 	double flops = (double)nblk * 4 * (double)iters * 8 * 2048.0;
 	return flops / (ms * 1e-3) * 1e-12;
+}
+
+// the bulk trailing update of one factorization step, stand-alone: C (m x (m + 1), upper tiles) -= P^T P with a
+// 128-row panel P, `iters` launches back to back, hipEvents on the ctx stream; returns ms per launch
+double microbench_update(spp_ctx *ctx, int64_t m, int iters)
+{
+	const int64_t ld = ((m + 1 + 127) / 128) * 128;
+	DevBuf<double> p, c;
+	p.reserve((size_t)ld * 128);
+	c.reserve((size_t)ld * ld);
+	SPP_HIP_CHECK(hipMemsetAsync(p.p, 0, (size_t)ld * 128 * sizeof(double), ctx->stream));
+	SPP_HIP_CHECK(hipMemsetAsync(c.p, 0, (size_t)ld * ld * sizeof(double), ctx->stream));
+	hipEvent_t e0, e1;
+	SPP_HIP_CHECK(hipEventCreate(&e0));
+	SPP_HIP_CHECK(hipEventCreate(&e1));
+	// the panel is stored as the rows [0, 128) of a 128 x (m + 1) strip with leading dimension 128
+	dense_gemm_tn_sub(ctx, m, m + 1, 128, p.p, 128, p.p, 128, c.p, ld, true);
+	SPP_HIP_CHECK(hipEventRecord(e0, ctx->stream));
+	for(int i = 0; i < iters; ++ i)
+		dense_gemm_tn_sub(ctx, m, m + 1, 128, p.p, 128, p.p, 128, c.p, ld, true);
+	SPP_HIP_CHECK(hipEventRecord(e1, ctx->stream));
+	SPP_HIP_CHECK(hipEventSynchronize(e1));
+	float ms = 0;
+	SPP_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+	(void)hipEventDestroy(e0);
+	(void)hipEventDestroy(e1);
+	return ms / iters;
 }
 
 } // namespace spp

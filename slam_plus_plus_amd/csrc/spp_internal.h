@@ -239,6 +239,7 @@ bool dense_gemm_tn_sub(spp_ctx *ctx, int64_t m, int64_t n, int64_t k, const doub
 double microbench_copy(spp_ctx *ctx, size_t bytes, int iters);
 double microbench_mfma_f64(spp_ctx *ctx, int iters);
 double microbench_ctile(spp_ctx *ctx, int n, int iters);
+double microbench_update(spp_ctx *ctx, int64_t m, int iters);
 
 // ---- spp_assemble.hip ----
 void assemble_analyze(spp_ctx *ctx, int64_t nv, const int32_t *dim, int64_t ne, const int64_t *v0,
