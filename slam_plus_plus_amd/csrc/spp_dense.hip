@@ -956,6 +956,15 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 		const char *e = getenv("SPP_TRSM_SHARED_ABOVE");
 		trsm_shared_above = e ? atol(e) : (int64_t(1) << 40);
 	}
+	bool bulk_pending = false;
+	static int64_t wait_mid_below = -1;
+	if(wait_mid_below < 0) {
+		// SPP_WAIT_MID_BELOW: trailing rows below which the chain waits for the bulk update between potrf_diag
+		// and the panel solve of the NEXT step (the barrier packet is then processed under the running
+		// potrf_diag) instead of right before the tile row
+		const char *e = getenv("SPP_WAIT_MID_BELOW");
+		wait_mid_below = e ? atol(e) : 0;
+	}
 	auto potrf_and_panel = [&](hipStream_t st, int64_t k) {
 		const int64_t k0 = k * NB;
 		const int n_valid = (int)((n - k0 < NB) ? (n - k0) : NB);
@@ -963,6 +972,10 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 		hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(POTRF_THREADS), POTRF_LDS_DOUBLES * sizeof(double), st,
 			d_A + k0 + k0 * ld, ld, n_valid, (has_rhs && n_valid < NB) ? 1 : 0, tinv, ctx->dense.info.p, k0);
 		const int64_t c1 = k0 + NB;
+		if(bulk_pending && rows - c1 < wait_mid_below) {
+			SPP_HIP_CHECK(hipStreamWaitEvent(st, evB, 0));
+			bulk_pending = false;
+		}
 		if(c1 < ncols) { // panel: R_kj = Tinv^T S_kj in place (A = tinv: 128 x 128; B = C = S[k0.., c1..])
 			// While the bulk update of the previous step fills the chip (large trailing matrix) the fully
 			// staged kernel -- 150 KB of LDS per workgroup -- only gets CUs as they drain completely and
@@ -1008,7 +1021,6 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 		}
 	};
 	potrf_and_panel(s, 0);
-	bool bulk_pending = false;
 	// pairing pays once the bulk update is shorter than the serial chain (it then hides anyway and the
 	// pair saves one cross-stream hand-off); while the trailing matrix is large the single-step schedule
 	// overlaps better. SPP_PAIR_BELOW = trailing rows below which steps are paired.

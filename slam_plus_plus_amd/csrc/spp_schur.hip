@@ -9,7 +9,7 @@
 //   s_accum_kernel   S = W * U^T (upper) + A              :1757-1767 (MultiplyToWith_FBS #2 + AddTo_FBS)
 //   rhs_kernel       x = eta_pose + sum W l               :1811-1830 (PreMultiply_Add_FBS)
 //   [dense LLT, spp_dense.hip]                            :1839-1853
-//   backsubst_kernel l = -l + U^T dx ; dl = (-C^-1) l     :1867-1881 (PostMultiply_Add_FBS_Parallel, PreMultiply_Add)
+//   backsubst_obs/lm l = -l + U^T dx ; dl = (-C^-1) l     :1867-1881 (PostMultiply_Add_FBS_Parallel, PreMultiply_Add)
 // The reference's Permute_UpperTriangular_To / SliceTo / TransposeTo (:1688-1709) move no data here:
 // the kernels address the blocks of the ORIGINAL Lambda through the index lists built once by
 // build_schur_plan() (spp_symbolic.cpp).
@@ -114,7 +114,11 @@ __device__ __forceinline__ void load_U(const double *__restrict__ vals, int64_t 
 	}
 }
 
-// ---- W = U (-C^-1), packed U, W l : one thread per observation ------------------------------------
+// ---- W = U (-C^-1), packed U, W l : one lane per observation ----------------------------------------
+// The camera-major slots of a wave's observations are scattered: with a lane storing its own block every
+// store instruction put 64 eight-byte pieces into 64 different lines (36 + 6 such instructions per wave).
+// W, the packed U and W l instead go through an LDS image [observation][odd stride] and are stored with
+// consecutive lanes on consecutive doubles of one block (a few 64-byte segments per instruction).
 template <int DP, int DL>
 __global__ __launch_bounds__(256)
 void obs_kernel(int64_t no, const int32_t *__restrict__ obs_lm, const int64_t *__restrict__ obs_off,
@@ -122,12 +126,26 @@ void obs_kernel(int64_t no, const int32_t *__restrict__ obs_lm, const int64_t *_
 	const double *__restrict__ cinv, const int32_t *__restrict__ obs_wpos, double *__restrict__ W,
 	double *__restrict__ Up, double *__restrict__ xw)
 {
-	const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if(a >= no)
-		return;
-	const int32_t l = obs_lm[a];
-	double U[DP * DL];
-	load_U<DP, DL>(vals, obs_off[a], U);
+	constexpr int BLK = DP * DL, ST = BLK | 1;
+	__shared__ double img_all[4][64 * ST];
+	__shared__ int32_t slot_all[4][64];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	double *img = img_all[wave];
+	int32_t *slot = slot_all[wave];
+	const int64_t a0 = ((int64_t)blockIdx.x * 4 + wave) * 64, a = a0 + lane;
+	const bool active = a < no;
+	const int nact = (no - a0 < 64) ? (int)((no - a0 > 0) ? (no - a0) : 0) : 64;
+	const int64_t oo = active ? obs_off[a] : 0;
+	const int32_t l = active ? obs_lm[a] : 0;
+	slot[lane] = active ? obs_wpos[a] : 0; // camera-major slot of this observation
+	double U[BLK];
+	if(active)
+		load_U<DP, DL>(vals, oo, U);
+	else {
+#pragma unroll
+		for(int e = 0; e < BLK; ++ e)
+			U[e] = 0;
+	}
 	double Ci[DL * DL];
 #pragma unroll
 	for(int e = 0; e < DL * DL; ++ e)
@@ -135,28 +153,49 @@ void obs_kernel(int64_t no, const int32_t *__restrict__ obs_lm, const int64_t *_
 	double lv[DL];
 #pragma unroll
 	for(int q = 0; q < DL; ++ q)
-		lv[q] = rhs[lm_rbase[l] + q];
-	double Wl[DP];
+		lv[q] = active ? rhs[lm_rbase[l] + q] : 0.0;
+	double Wl[DP], Wv[BLK];
 #pragma unroll
 	for(int r = 0; r < DP; ++ r)
 		Wl[r] = 0;
-	const int64_t wp = obs_wpos[a]; // camera-major slot of this observation
-	double *wo = W + wp * DP * DL, *uo = Up + wp * DP * DL;
 #pragma unroll
 	for(int q = 0; q < DL; ++ q)
 #pragma unroll
 		for(int r = 0; r < DP; ++ r) {
-			double s = 0;
+			double sum = 0;
 #pragma unroll
 			for(int t = 0; t < DL; ++ t)
-				s += U[r + DP * t] * Ci[t + DL * q];
-			wo[r + DP * q] = s;
-			uo[r + DP * q] = U[r + DP * q];
-			Wl[r] += s * lv[q];
+				sum += U[r + DP * t] * Ci[t + DL * q];
+			Wv[r + DP * q] = sum;
+			Wl[r] += sum * lv[q];
 		}
+	// block-cooperative stores: element p of the wave's 64 x BLK image goes to slot[p / BLK] * BLK + p % BLK
+#pragma unroll
+	for(int e = 0; e < BLK; ++ e)
+		img[lane * ST + e] = Wv[e];
+	__syncthreads();
+	for(int p = lane; p < nact * BLK; p += 64) {
+		const int j = p / BLK, e = p - j * BLK;
+		W[(int64_t)slot[j] * BLK + e] = img[j * ST + e];
+	}
+	__syncthreads();
+#pragma unroll
+	for(int e = 0; e < BLK; ++ e)
+		img[lane * ST + e] = U[e];
+	__syncthreads();
+	for(int p = lane; p < nact * BLK; p += 64) {
+		const int j = p / BLK, e = p - j * BLK;
+		Up[(int64_t)slot[j] * BLK + e] = img[j * ST + e];
+	}
+	__syncthreads();
 #pragma unroll
 	for(int r = 0; r < DP; ++ r)
-		xw[wp * DP + r] = Wl[r];
+		img[lane * (DP | 1) + r] = Wl[r];
+	__syncthreads();
+	for(int p = lane; p < nact * DP; p += 64) {
+		const int j = p / DP, r = p - j * DP;
+		xw[(int64_t)slot[j] * DP + r] = img[j * (DP | 1) + r];
+	}
 }
 
 // ---- S block accumulation: one wave per work item -------------------------------------------------
@@ -390,12 +429,40 @@ void rhs_kernel(int64_t nc, const int32_t *__restrict__ cam_ptr, const int32_t *
 	}
 }
 
-// ---- back-substitution: one thread per landmark ------------------------------------------------
+// ---- back-substitution ---------------------------------------------------------------------------
+// dl = (-C^-1) (-l + sum_a U_a^T dx_pose(a)), LinearSolver_Schur.h:1867-1881. Two launches: the products
+// U_a^T dx, one lane per observation (uniform work, neighbouring lanes read neighbouring blocks of a
+// landmark's column of Lambda), then one thread per landmark adds its (contiguous) products in
+// observation order and applies -C^-1. tq (DL doubles per observation) reuses the W l buffer.
 template <int DP, int DL>
 __global__ __launch_bounds__(256)
-void backsubst_kernel(int64_t nl, const int32_t *__restrict__ lm_ptr, const int32_t *__restrict__ obs_pose,
-	const int64_t *__restrict__ lm_rbase, const int64_t *__restrict__ obs_off, const double *__restrict__ vals,
-	const double *__restrict__ cinv, const double *__restrict__ dx, double *__restrict__ rhs)
+void backsubst_obs_kernel(int64_t no, const int32_t *__restrict__ obs_pose, const int64_t *__restrict__ obs_off,
+	const double *__restrict__ vals, const double *__restrict__ dx, double *__restrict__ tq)
+{
+	const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if(a >= no)
+		return;
+	double u[DP * DL];
+	load_U<DP, DL>(vals, obs_off[a], u);
+	double dv[DP];
+	const double *d = dx + (int64_t)obs_pose[a] * DP;
+#pragma unroll
+	for(int r = 0; r < DP; ++ r)
+		dv[r] = d[r];
+#pragma unroll
+	for(int q = 0; q < DL; ++ q) {
+		double sum = 0;
+#pragma unroll
+		for(int r = 0; r < DP; ++ r)
+			sum += dv[r] * u[r + DP * q];
+		tq[a * DL + q] = sum;
+	}
+}
+
+template <int DL>
+__global__ __launch_bounds__(256)
+void backsubst_lm_kernel(int64_t nl, const int32_t *__restrict__ lm_ptr, const int64_t *__restrict__ lm_rbase,
+	const double *__restrict__ tq, const double *__restrict__ cinv, double *__restrict__ rhs)
 {
 	const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if(l >= nl)
@@ -406,30 +473,18 @@ void backsubst_kernel(int64_t nl, const int32_t *__restrict__ lm_ptr, const int3
 	for(int q = 0; q < DL; ++ q)
 		t[q] = -rhs[rb + q]; // v_l = -v_l, LinearSolver_Schur.h:1867
 	for(int32_t a = lm_ptr[l]; a < lm_ptr[l + 1]; ++ a) {
-		double u[DP * DL]; // U of this observation straight from Lambda (a landmark's blocks are contiguous there)
-		load_U<DP, DL>(vals, obs_off[a], u);
-		const double *d = dx + (int64_t)obs_pose[a] * DP;
-		double dv[DP];
 #pragma unroll
-		for(int r = 0; r < DP; ++ r)
-			dv[r] = d[r];
-#pragma unroll
-		for(int q = 0; q < DL; ++ q) {
-			double s = 0;
-#pragma unroll
-			for(int r = 0; r < DP; ++ r)
-				s += dv[r] * u[r + DP * q];
-			t[q] += s;
-		}
+		for(int q = 0; q < DL; ++ q)
+			t[q] += tq[(int64_t)a * DL + q];
 	}
 	const double *Ci = cinv + l * DL * DL;
 #pragma unroll
 	for(int q = 0; q < DL; ++ q) {
-		double s = 0;
+		double sum = 0;
 #pragma unroll
 		for(int u = 0; u < DL; ++ u)
-			s += Ci[q + DL * u] * t[u];
-		rhs[rb + q] = s;
+			sum += Ci[q + DL * u] * t[u];
+		rhs[rb + q] = sum;
 	}
 }
 
@@ -507,9 +562,13 @@ static int schur_finish_t(spp_ctx *ctx, const double *d_vals, double *S, double 
 		phase_end(ctx, SPP_PHASE_TRISOLVE);
 	}
 	phase_begin(ctx, SPP_PHASE_BACKSUBST);
+	static_assert(DL <= DP, "the products U^T dx reuse the W l buffer (DP doubles per observation)");
+	if(sp.no)
+		hipLaunchKernelGGL((backsubst_obs_kernel<DP, DL>), dim3((unsigned)((sp.no + 255) / 256)), dim3(256), 0, s,
+			sp.no, sp.obs_pose.p, sp.obs_off.p, d_vals, xcol, sp.xw.p);
 	if(sp.nl)
-		hipLaunchKernelGGL((backsubst_kernel<DP, DL>), dim3((unsigned)((sp.nl + 255) / 256)), dim3(256), 0, s,
-			sp.nl, sp.lm_ptr.p, sp.obs_pose.p, sp.lm_rbase.p, sp.obs_off.p, d_vals, sp.cinv.p, xcol, d_rhs);
+		hipLaunchKernelGGL((backsubst_lm_kernel<DL>), dim3((unsigned)((sp.nl + 255) / 256)), dim3(256), 0, s,
+			sp.nl, sp.lm_ptr.p, sp.lm_rbase.p, sp.xw.p, sp.cinv.p, d_rhs);
 	if(sp.nc)
 		hipLaunchKernelGGL((scatter_dx_kernel<DP>), dim3((unsigned)((sp.nc * DP + 255) / 256)), dim3(256), 0, s,
 			sp.nc, sp.pose_rbase.p, xcol, d_rhs);
