@@ -312,7 +312,7 @@ def main():
                            "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
                            "launches_per_solve": int(dom_n), "avg_launch_ms": dom_ms / dom_n,
                            "flops_per_launch": dom_flops / dom_n,
-                           "standalone_update_tflops": (lambda m: (128.0 * m * (m + 1) + 256.0 * m) / ctx.microbench_update(m, 20) * 1e-9)(5120),
+                           "standalone_update_tflops": (lambda m: (128.0 * m * (m + 1) + 256.0 * m) / ctx.microbench_update(m, 5) * 1e-9)(5120),
                            "measured_mfma_f64_peak": ctx.microbench_mfma_f64(4000),
                            "measured_copy_gbs": ctx.microbench_copy(1 << 30, 10),
                            "measured_ctile_rw_gbs": ctx.microbench_ctile(8192, 5)}

@@ -151,6 +151,10 @@ void spp_destroy(spp_ctx *ctx)
 		(void)hipEventDestroy(ctx->dense.ev[0]);
 		(void)hipEventDestroy(ctx->dense.ev[1]);
 	}
+	if(ctx->dense.row) {
+		(void)hipStreamDestroy(ctx->dense.row);
+		(void)hipEventDestroy(ctx->dense.ev_row);
+	}
 	if(ctx->dense.h_chain_err)
 		(void)hipHostFree(ctx->dense.h_chain_err);
 	if(ctx->timer.created)

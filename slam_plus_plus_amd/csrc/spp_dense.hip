@@ -855,8 +855,10 @@ static void ensure_dense_work(spp_ctx *ctx, int64_t nblk)
 		int prio_lo = 0, prio_hi = 0;
 		SPP_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
 		const char *e = getenv("SPP_AUX_PRIO");
-		// SPP_AUX_RESERVE_CUS = n: the bulk stream is created with a CU mask that leaves the first n CUs to the
-		// chain (experiment: potrf_diag then always finds an idle CU)
+		// The bulk stream is created with a CU mask that leaves the first n CUs (SPP_AUX_RESERVE_CUS, default 32)
+		// to the chain: under a running bulk update every wave slot of the chip is taken, potrf_diag and the
+		// tile-row workgroups otherwise wait for bulk workgroups to retire (measured: potrf_diag 33 -> 50..100 us,
+		// tile row 10 -> 55 us). 8 CUs already help, 32..64 are best; beyond that the bulk update itself suffers.
 		const char *r = getenv("SPP_AUX_RESERVE_CUS");
 		const int reserve = r ? atoi(r) : 32;
 		if(reserve > 0) {
@@ -866,10 +868,19 @@ static void ensure_dense_work(spp_ctx *ctx, int64_t nblk)
 			std::vector<uint32_t> mask((size_t)nw, 0u);
 			for(int c = reserve; c < ncu; ++ c)
 				mask[(size_t)c / 32] |= 1u << (c % 32);
-			SPP_HIP_CHECK(hipExtStreamCreateWithCUMask(&ctx->dense.aux, (uint32_t)nw, mask.data()));
-		} else
+			if(hipExtStreamCreateWithCUMask(&ctx->dense.aux, (uint32_t)nw, mask.data()) != hipSuccess) {
+				(void)hipGetLastError(); // no CU masking on this stack: plain low-priority stream
+				ctx->dense.aux = nullptr;
+			}
+		}
+		if(!ctx->dense.aux)
 		SPP_HIP_CHECK(hipStreamCreateWithPriority(&ctx->dense.aux, hipStreamNonBlocking,
 			(e && !strcmp(e, "hi")) ? prio_hi : prio_lo));
+		// third stream (tile-row remainder, see dense_factor_steps_enqueue). Not CU-masked: a second masked stream
+		// beside the bulk stream doubled the factorization time (the two seem to share one hardware queue).
+		if(!ctx->dense.row)
+			SPP_HIP_CHECK(hipStreamCreateWithFlags(&ctx->dense.row, hipStreamNonBlocking));
+		SPP_HIP_CHECK(hipEventCreateWithFlags(&ctx->dense.ev_row, hipEventDisableTiming));
 		SPP_HIP_CHECK(hipEventCreateWithFlags(&ctx->dense.ev[0], hipEventDisableTiming));
 		SPP_HIP_CHECK(hipEventCreateWithFlags(&ctx->dense.ev[1], hipEventDisableTiming));
 	}
@@ -965,12 +976,17 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 		const char *e = getenv("SPP_WAIT_MID_BELOW");
 		wait_mid_below = e ? atol(e) : 0;
 	}
+	bool row_pending = false; // the remainder of tile row k (stream ctx->dense.row) has to finish before panel k
 	auto potrf_and_panel = [&](hipStream_t st, int64_t k) {
 		const int64_t k0 = k * NB;
 		const int n_valid = (int)((n - k0 < NB) ? (n - k0) : NB);
 		double *tinv = ctx->dense.tinv_all.p + (size_t)k * NB * NB;
 		hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(POTRF_THREADS), POTRF_LDS_DOUBLES * sizeof(double), st,
 			d_A + k0 + k0 * ld, ld, n_valid, (has_rhs && n_valid < NB) ? 1 : 0, tinv, ctx->dense.info.p, k0);
+		if(row_pending) {
+			SPP_HIP_CHECK(hipStreamWaitEvent(st, ctx->dense.ev_row, 0));
+			row_pending = false;
+		}
 		const int64_t c1 = k0 + NB;
 		if(bulk_pending && rows - c1 < wait_mid_below) {
 			SPP_HIP_CHECK(hipStreamWaitEvent(st, evB, 0));
@@ -1031,13 +1047,15 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 		e = getenv("SPP_PAIR_ABOVE");
 		pair_above = e ? atol(e) : (int64_t(1) << 40); // pair while the trailing matrix is LARGER than this (bulk-bound phase)
 	}
-	static int eva_early = -1;
+	static int eva_early = -1, split_row = 0;
 	static int64_t early_above = 0;
 	if(eva_early < 0) {
 		const char *e = getenv("SPP_EVA_EARLY");
 		eva_early = e ? atoi(e) : 1;
 		e = getenv("SPP_EARLY_ABOVE"); // the bulk update is handed over before the tile row only while it bounds the step
 		early_above = e ? atol(e) : 0;
+		e = getenv("SPP_SPLIT_TILEROW"); // measured: no gain (the extra cross-stream events cost what the overlap saves)
+		split_row = e ? atoi(e) : 0;
 	}
 	// Once the trailing matrix is small the whole update is shorter than a cross-stream hand-off plus the
 	// tile row (two events cost ~12 us per step): the step then runs on the chain stream alone,
@@ -1092,6 +1110,8 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 		// this wait is issued before the next record)
 		if(bulk_pending) {
 			SPP_HIP_CHECK(hipStreamWaitEvent(s, evB, 0));
+			if(early && split_row) // the third stream updates row k+1 as well; evB is re-recorded below
+				SPP_HIP_CHECK(hipStreamWaitEvent(ctx->dense.row, evB, 0));
 			bulk_pending = false;
 		}
 		const int64_t cb = (npan == 2) ? c3 : c2;
@@ -1121,8 +1141,21 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 			ctx->stream = keep;
 			SPP_HIP_CHECK(hipEventRecord(evB, s2));
 			bulk_pending = true;
-			if(early)
-				tile_row(c1, k0, 1);
+			if(early) {
+				const int64_t m = std::min<int64_t>(NB, rows - c1);
+				if(split_row && m == NB && ncols - c2 > 0) {
+					// potrf_diag(k+1) needs the diagonal tile of row k+1 only; the rest of the row is needed by the
+					// panel solve AFTER it and is updated beside potrf_diag on the third stream
+					hipStream_t s3 = ctx->dense.row;
+					SPP_HIP_CHECK(hipStreamWaitEvent(s3, evA, 0)); // row panel k complete (bulk update k-1: waited for above)
+					const double *Pa = d_A + k0 + c1 * ld, *Pb = d_A + k0 + c2 * ld;
+					launch_gemm_staged<32, 32, 16, 16, 0>(s3, NB, ncols - c2, NB, Pa, ld, Pb, ld, d_A + c1 + c2 * ld, ld, false);
+					SPP_HIP_CHECK(hipEventRecord(ctx->dense.ev_row, s3));
+					row_pending = true;
+					launch_gemm_staged<32, 32, 16, 16, 0>(s, NB, NB, NB, Pa, ld, Pa, ld, d_A + c1 + c1 * ld, ld, true);
+				} else
+					tile_row(c1, k0, 1);
+			}
 		}
 		// next pair's first diagonal block + row panel overlaps the bulk update
 		if(k + npan < nsteps)
@@ -1131,6 +1164,8 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 	}
 	if(bulk_pending)
 		SPP_HIP_CHECK(hipStreamWaitEvent(s, evB, 0));
+	if(row_pending)
+		SPP_HIP_CHECK(hipStreamWaitEvent(s, ctx->dense.ev_row, 0));
 	SPP_HIP_CHECK(hipGetLastError());
 }
 

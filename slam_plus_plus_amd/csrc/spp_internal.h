@@ -140,6 +140,8 @@ struct DenseWork {
 	bool gseen = false;    // pinned: timeout flag of the chain kernel, valid after a stream sync
 	hipStream_t aux = nullptr;     // lookahead stream: potrf_diag + trsm of the next panel
 	hipEvent_t ev[2] = {nullptr, nullptr};
+	hipStream_t row = nullptr;     // third stream: the part of tile row k+1 that only the NEXT panel solve needs
+	hipEvent_t ev_row = nullptr;
 };
 
 // ------------------------------------------------------------------------------------------------

@@ -1,0 +1,5 @@
+for w in ladybug49 sphere2500 manhattan3500 synthetic10k; do
+  python bench.py --workload $w > gpurun_out/bench_$w.log 2>&1
+  grep '^{' gpurun_out/bench_$w.log | tail -1 | cut -c1-200
+done
+python bench.py > gpurun_out/bench_default.log 2>&1; grep '^{' gpurun_out/bench_default.log | tail -1 | cut -c1-300
