@@ -163,13 +163,13 @@ int64_t sparse_info(const spp_ctx *ctx, int what)
 
 static const int NCLS = 5;
 static const int MID_FRONT_MAX = 640; // largest padded height the one-workgroup in-place (HBM image) kernel is built for
-static const int MID_FRONT_DEFAULT = 448; // default split: fronts above go to the dense MFMA kernels
+static const int MID_FRONT_DEFAULT = 320; // default split: fronts above go to the dense MFMA kernels
 
 void sparse_analyze(spp_ctx *ctx, const Structure &st)
 {
 	const int64_t nb = st.nb;
 	// fronts above this padded height go to the dense MFMA kernels (one after the other, many workgroups
-	// each) instead of the one-workgroup in-place kernel; SPP_MID_FRONT_MAX tunes the split (128 .. 640; 448 measured best on sphere2500)
+	// each) instead of the one-workgroup in-place kernel; SPP_MID_FRONT_MAX tunes the split (128 .. 640; with the single-stream dense steps 320 measured best on sphere2500, neutral on the other sparse workloads)
 	int mid_front_max = MID_FRONT_DEFAULT;
 	if(const char *e = getenv("SPP_MID_FRONT_MAX"))
 		mid_front_max = std::max(128, std::min(MID_FRONT_MAX, atoi(e)));
