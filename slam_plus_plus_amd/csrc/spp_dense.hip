@@ -488,9 +488,19 @@ __device__ long long spp_potrf_trace[64]; // cycle stamps of thread 0 / thread 6
 #endif
 
 constexpr int NB = DENSE_NB;
-constexpr int TS = NB + 1;   // LDS column stride of the block image: element (r, c) at r + c * TS
+#ifndef SPP_POTRF_TS
+#define SPP_POTRF_TS (NB + 1)
+#endif
+constexpr int TS = SPP_POTRF_TS;   // LDS column stride of the block image: element (r, c) at r + c * TS
 constexpr int POTRF_THREADS = 1024;
 constexpr int POTRF_LDS_DOUBLES = NB * TS + 4 * 16 * PT + 2 * NB + 8;
+
+// workgroup barrier that orders LDS accesses only (s_waitcnt lgkmcnt(0) + s_barrier): unlike __syncthreads()
+// it does not wait for outstanding global stores
+__device__ __forceinline__ void lds_barrier()
+{
+	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 __global__ __launch_bounds__(POTRF_THREADS)
 void potrf_diag_kernel(double *__restrict__ Ablk, int64_t ld, int n_valid, int has_rhs,
@@ -507,37 +517,85 @@ void potrf_diag_kernel(double *__restrict__ Ablk, int64_t ld, int n_valid, int h
 	int *fail = (int*)(yv + NB);
 	const int l15 = lane & 15, l4 = lane >> 4;
 	constexpr int NW = POTRF_THREADS / 64;
-	{
-		// 16-byte loads, all of a thread's loads in flight before its first LDS store
-		double2 v[NB * NB / 2 / POTRF_THREADS];
-#pragma unroll
-		for(int t = 0; t < NB * NB / 2 / POTRF_THREADS; ++ t) {
-			const int e = tid + t * POTRF_THREADS, r = (e & (NB / 2 - 1)) * 2, c = e >> 6;
-			v[t] = *(const double2*)(Ablk + r + (int64_t)c * ld);
-		}
-#pragma unroll
-		for(int t = 0; t < NB * NB / 2 / POTRF_THREADS; ++ t) {
-			const int e = tid + t * POTRF_THREADS, r = (e & (NB / 2 - 1)) * 2, c = e >> 6;
-			T[r + c * TS] = v[t].x;
-			T[r + 1 + c * TS] = v[t].y;
-		}
-	}
+	const int rhs_col = (has_rhs && n_valid < NB) ? n_valid : -1;
+	// Prologue. The first diagonal tile only needs its own 16 x 16 entries: wave 0 fetches them and starts
+	// the elimination (5 500 cycles) while the other 15 waves stream in the rest of the block (6 500 cycles).
+	// Not possible when the carried right-hand side sits inside that tile (n_valid < 16): plain order then.
+	const bool fast0 = !(rhs_col >= 0 && rhs_col < 16);
 	if(tid == 0)
 		*fail = 0;
-	__syncthreads();
-	SPP_STAMP(1, 0);
-	const int rhs_col = (has_rhs && n_valid < NB) ? n_valid : -1;
-	if(tid < NB) {
-		yv[tid] = (rhs_col >= 0 && tid < n_valid) ? T[tid + rhs_col * TS] : 0.0;
-		dinv[tid] = 1.0;
+	if(fast0) {
+		if(wave == 0) {
+			double v[4];
+#pragma unroll
+			for(int t = 0; t < 4; ++ t)
+				v[t] = Ablk[l15 + (int64_t)(l4 + 4 * t) * ld];
+#pragma unroll
+			for(int t = 0; t < 4; ++ t)
+				T[l15 + (l4 + 4 * t) * TS] = v[t];
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			diag_tile_factor<TS>(T, DvB, GdB, dinv, 0, lane, fail, info, k0);
+		} else {
+			// 16-byte pieces of the block without its first tile, spread over the 960 threads of waves 1..15;
+			// all of a thread's loads are in flight before its first LDS store
+			constexpr int NP = NB * NB / 2, NTH = POTRF_THREADS - 64, NIT = (NP + NTH - 1) / NTH;
+			double2 v[NIT];
+#pragma unroll
+			for(int t = 0; t < NIT; ++ t) {
+				const int e = (tid - 64) + t * NTH, r = (e & (NB / 2 - 1)) * 2, c = e >> 6;
+				if(e < NP && !(r < 16 && c < 16))
+					v[t] = *(const double2*)(Ablk + r + (int64_t)c * ld);
+			}
+#pragma unroll
+			for(int t = 0; t < NIT; ++ t) {
+				const int e = (tid - 64) + t * NTH, r = (e & (NB / 2 - 1)) * 2, c = e >> 6;
+				if(e < NP && !(r < 16 && c < 16)) {
+					T[r + c * TS] = v[t].x;
+					T[r + 1 + c * TS] = v[t].y;
+				}
+			}
+		}
+		__syncthreads();
+		SPP_STAMP(1, 0);
+		if(tid < NB) {
+			yv[tid] = (rhs_col >= 0 && tid < n_valid) ? T[tid + rhs_col * TS] : 0.0;
+			if(tid >= 16)
+				dinv[tid] = 1.0; // entries 0..15 were set by the elimination of the first tile
+		}
+		__syncthreads();
+		if(rhs_col >= 0 && tid < NB)
+			T[tid + rhs_col * TS] = (tid == rhs_col) ? 1.0 : 0.0; // the rhs column becomes plain padding
+		__syncthreads();
+	} else {
+		{
+			double2 v[NB * NB / 2 / POTRF_THREADS];
+#pragma unroll
+			for(int t = 0; t < NB * NB / 2 / POTRF_THREADS; ++ t) {
+				const int e = tid + t * POTRF_THREADS, r = (e & (NB / 2 - 1)) * 2, c = e >> 6;
+				v[t] = *(const double2*)(Ablk + r + (int64_t)c * ld);
+			}
+#pragma unroll
+			for(int t = 0; t < NB * NB / 2 / POTRF_THREADS; ++ t) {
+				const int e = tid + t * POTRF_THREADS, r = (e & (NB / 2 - 1)) * 2, c = e >> 6;
+				T[r + c * TS] = v[t].x;
+				T[r + 1 + c * TS] = v[t].y;
+			}
+		}
+		__syncthreads();
+		SPP_STAMP(1, 0);
+		if(tid < NB) {
+			yv[tid] = (rhs_col >= 0 && tid < n_valid) ? T[tid + rhs_col * TS] : 0.0;
+			dinv[tid] = 1.0;
+		}
+		__syncthreads();
+		if(rhs_col >= 0 && tid < NB)
+			T[tid + rhs_col * TS] = (tid == rhs_col) ? 1.0 : 0.0; // the rhs column becomes plain padding
+		__syncthreads();
+		if(wave == 0)
+			diag_tile_factor<TS>(T, DvB, GdB, dinv, 0, lane, fail, info, k0);
+		__syncthreads();
 	}
-	__syncthreads();
-	if(rhs_col >= 0 && tid < NB)
-		T[tid + rhs_col * TS] = (tid == rhs_col) ? 1.0 : 0.0; // the rhs column becomes plain padding
-	__syncthreads();
-	if(wave == 0)
-		diag_tile_factor<TS>(T, DvB, GdB, dinv, 0, lane, fail, info, k0);
-	__syncthreads();
 	SPP_STAMP(2, 0);
 
 	for(int J = 0; J < NB / 16; ++ J) {
@@ -565,7 +623,7 @@ void potrf_diag_kernel(double *__restrict__ Ablk, int64_t ld, int n_valid, int h
 			yv[j0 + lane] = s;
 		}
 		SPP_STAMP(4 + 6 * J, 0);
-		__syncthreads();
+		lds_barrier(); // LDS traffic only: the write-back stores stay in flight
 		SPP_STAMP(5 + 6 * J, 0);
 		SPP_STAMP(6 + 6 * J, 64);
 		// ---- C (+ A of the next panel on wave 0): trailing update with the panel rows P = T[j0 .. j0 + 16, :]
@@ -604,8 +662,14 @@ void potrf_diag_kernel(double *__restrict__ Ablk, int64_t ld, int n_valid, int h
 						j0 + 16, lane, fail, info, k0);
 				}
 			} else {
-				for(int q = wave; q < nR + nG; q += 2 * (NW - 1)) { // q = 1 .. : waves 1..15, two tiles each round
-					const int q1 = q + (NW - 1);
+				// The waves that share wave 0's SIMD (4, 8, 12) stay out of the trailing update: the dependent MFMA
+				// chain of the diagonal tile then has its matrix core to itself (7 000 -> 5 300 cycles per panel).
+				// Row block J -- final since step B -- goes back to global memory inside this phase (below): R (rows
+				// j0 .. j0+15 right of and on the diagonal) and columns j0 .. j0+15 of the inverse.
+				constexpr int NCW = NW - 1 - (NW / 4 - 1);
+				const int slot = wave - 1 - (wave >> 2);
+				for(int q = ((wave & 3) ? slot + 1 : (1 << 20)); q < nR + nG; q += 2 * NCW) { // two tiles per wave and round
+					const int q1 = q + NCW;
 					int I0, C0, I1 = 0, C1 = 0;
 					bool g0, g1 = false;
 					decode(q, I0, C0, g0);
@@ -639,6 +703,28 @@ void potrf_diag_kernel(double *__restrict__ Ablk, int64_t ld, int n_valid, int h
 						}
 					}
 				}
+				// write-back of row block J by all of waves 1..15, after their tiles (the stores stay in flight across
+				// the barriers below). Measured alternatives: waves 4 / 8 / 12 alone doing it (they have no tiles) took
+				// longer than wave 0's elimination and slowed it through the shared SIMD; three tiles per wave and round
+				// cost what two rounds of two cost (the update is bound by the MFMA pipe: one v_mfma_f64_16x16x4 per
+				// ~105 cycles and SIMD, which is also what bounds the bare-MFMA loop at 47 TFLOP/s).
+				{
+					const int t15 = (wave - 1) * 64 + lane; // 0 .. 959
+					for(int e = t15; e < 16 * (NB - j0); e += (NW - 1) * 64) { // R: 16 rows x (NB - j0) columns
+						const int r = j0 + (e & 15), c = j0 + (e >> 4);
+						if(r <= c && c != rhs_col)
+							Ablk[r + (int64_t)c * ld] = T[r + c * TS];
+					}
+					for(int e = t15; e < 16 * NB; e += (NW - 1) * 64) { // inverse: columns j0 .. j0+15, all 128 rows
+						const int r = e & (NB - 1), c = j0 + (e >> 7);
+						double v = 0;
+						if(r == c)
+							v = dinv[r];
+						else if(r < c)
+							v = T[c + r * TS]; // G[c][r]
+						tinv[r + c * NB] = v;
+					}
+				}
 				// rhs: y_i -= sum_k P[k][i] y_J[k], by the threads of waves 8..9
 				const int ti = tid - 512;
 				if(ti >= j0 + 16 && ti < NB) {
@@ -651,23 +737,12 @@ void potrf_diag_kernel(double *__restrict__ Ablk, int64_t ld, int n_valid, int h
 		}
 		SPP_STAMP(7 + 6 * J, 0);
 		SPP_STAMP(8 + 6 * J, 64);
-		__syncthreads();
+		lds_barrier(); // LDS traffic only: the write-back stores stay in flight
 	}
 	SPP_STAMP(51, 0);
 	if(*fail)
 		return;
-	// ---- write back R (upper triangle), the carried rhs, and the dense upper-triangular inverse
-	for(int e = tid; e < NB * NB; e += POTRF_THREADS) {
-		const int r = e & (NB - 1), c = e >> 7;
-		if(r <= c && c != rhs_col)
-			Ablk[r + (int64_t)c * ld] = T[r + c * TS];
-		double v = 0;
-		if(r == c)
-			v = dinv[r];
-		else if(r < c)
-			v = T[c + r * TS]; // G[c][r]
-		tinv[r + c * NB] = v;
-	}
+	// R and the inverse went back block row by block row inside the loop; the carried rhs remains
 	if(rhs_col >= 0 && tid < n_valid)
 		Ablk[tid + (int64_t)rhs_col * ld] = yv[tid];
 	SPP_STAMP(52, 0);

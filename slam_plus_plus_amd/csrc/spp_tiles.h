@@ -78,6 +78,33 @@ __device__ __forceinline__ void tile_atb2_rt(const int TS, const double *a0, con
 	}
 }
 
+// three independent tiles at once (operand element (k, i) of a tile at a[k + i * TS], (k, j) at b[k + j * bjs])
+__device__ __forceinline__ void tile_atb3_rt(const int TS, const double *a0, const double *b0, int b0js,
+	const double *a1, const double *b1, int b1js, const double *a2, const double *b2, int b2js, int lane,
+	v4f64 &d0, v4f64 &d1, v4f64 &d2)
+{
+	d0 = (v4f64){0, 0, 0, 0};
+	d1 = (v4f64){0, 0, 0, 0};
+	d2 = (v4f64){0, 0, 0, 0};
+	const int l15 = lane & 15, l4 = lane >> 4;
+	double fa0[4], fb0[4], fa1[4], fb1[4], fa2[4], fb2[4];
+#pragma unroll
+	for(int kk = 0; kk < 4; ++ kk) {
+		fa0[kk] = a0[(kk * 4 + l4) + l15 * TS];
+		fb0[kk] = b0[(kk * 4 + l4) + l15 * b0js];
+		fa1[kk] = a1[(kk * 4 + l4) + l15 * TS];
+		fb1[kk] = b1[(kk * 4 + l4) + l15 * b1js];
+		fa2[kk] = a2[(kk * 4 + l4) + l15 * TS];
+		fb2[kk] = b2[(kk * 4 + l4) + l15 * b2js];
+	}
+#pragma unroll
+	for(int kk = 0; kk < 4; ++ kk) {
+		d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa0[kk], fb0[kk], d0, 0, 0, 0);
+		d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa1[kk], fb1[kk], d1, 0, 0, 0);
+		d2 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa2[kk], fb2[kk], d2, 0, 0, 0);
+	}
+}
+
 // step A: factor + invert the 16 x 16 diagonal tile at (j0, j0) in registers (one wave).
 // The symmetric tile W lives in the MFMA accumulator layout: lane (c = l & 15, q = l >> 4) holds
 // W[q + 4 r][c] in acc[r]. The rank-1 update of pivot j,
