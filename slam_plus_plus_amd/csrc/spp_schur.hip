@@ -210,6 +210,9 @@ void obs_kernel(int64_t no, const int32_t *__restrict__ obs_lm, const int64_t *_
 // (the common case) the additions happen in exactly the order of the pair list (= ascending landmark
 // = the reference's order); longer lists add lane-strided partial sums. No atomics: bit-reproducible.
 constexpr int SACC_WAVES = 4; // waves (items) per workgroup
+#ifndef SPP_SACC_RP
+#define SPP_SACC_RP 64 // 32 (half the LDS, twice the waves per CU) measured 14 % slower: the gather, not the occupancy, bounds the kernel
+#endif
 
 template <int DP, int DL>
 __global__ __launch_bounds__(SACC_WAVES * 64)
@@ -225,11 +228,12 @@ void s_accum_kernel(int64_t n_items, const int32_t *__restrict__ item_blk, const
 	                                            // blocks of the 3 x 3 case are only 8-byte aligned: 8-byte pieces)
 	constexpr int PCS = BLK / PW;               // pieces per block
 	constexpr int PPI = 64 / PCS;               // blocks (pairs) fetched per wave instruction
-	constexpr int NG = (64 + PPI - 1) / PPI;    // instructions per operand and round
+	constexpr int RP = SPP_SACC_RP;             // pairs per round: the LDS images hold RP blocks per operand
+	constexpr int NG = (RP + PPI - 1) / PPI;    // instructions per operand and round
 	constexpr int ST = BLK | 1;                 // LDS stride of one block image in doubles (odd)
 	constexpr int RS = (NE + 1) / 2 + 1;        // row stride of the reduction image
-	static_assert(2 * 64 * ST >= 64 * RS, "the reduction image reuses the staging area");
-	__shared__ double lds[SACC_WAVES][2 * 64 * ST];
+	static_assert(2 * RP * ST >= RP * RS, "the reduction image reuses the staging area");
+	__shared__ double lds[SACC_WAVES][2 * RP * ST];
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	// workgroups go round-robin over the 8 XCDs: XCD x works through its own contiguous range of the
 	// items (equal work per range), so that the camera segments of a tile of blocks are fetched into
@@ -238,18 +242,19 @@ void s_accum_kernel(int64_t n_items, const int32_t *__restrict__ item_blk, const
 	const int64_t item = xcd_beg[x] + (int64_t)(blockIdx.x >> 3) * SACC_WAVES + wave;
 	if(item >= xcd_beg[x + 1])
 		return; // whole wave
-	double *sw = lds[wave], *su = sw + 64 * ST, *rw = sw;
+	double *sw = lds[wave], *su = sw + RP * ST, *rw = sw;
 	const int32_t beg = item_beg[item], end = item_end[item];
 	const int my_pair = lane / PCS, my_piece = lane % PCS; // role in the cooperative fetch (lanes >= PPI * PCS idle)
 	double acc[NE];
 #pragma unroll
 	for(int e = 0; e < NE; ++ e)
 		acc[e] = 0;
-	for(int32_t q0 = beg; q0 < end; q0 += 64) {
+	for(int32_t q0 = beg; q0 < end; q0 += RP) {
 		const int32_t q = q0 + lane;
-		const int32_t pa = (q < end) ? pair_a[q] : -1, pb = (q < end) ? pair_b[q] : -1;
+		const bool mine = lane < RP && q < end; // this lane owns a pair of the round
+		const int32_t pa = mine ? pair_a[q] : -1, pb = mine ? pair_b[q] : -1;
 		// ---- cooperative fetch of up to 64 W and 64 U blocks into the LDS images
-		const int nround = (end - q0 < 64) ? end - q0 : 64;
+		const int nround = (end - q0 < RP) ? end - q0 : RP;
 		constexpr int GC = (NG < 10) ? NG : 10; // groups in flight at a time (register budget of the 6 x 6 case)
 #pragma unroll
 		for(int g0 = 0; g0 < NG; g0 += GC) {
@@ -274,7 +279,7 @@ void s_accum_kernel(int64_t n_items, const int32_t *__restrict__ item_blk, const
 			for(int gg = 0; gg < GC; ++ gg) {
 				const int g = g0 + gg;
 				const int p = g * PPI + my_pair;
-				if(g < NG && my_pair < PPI && p < 64) {
+				if(g < NG && my_pair < PPI && p < RP) {
 #pragma unroll
 					for(int t = 0; t < PW; ++ t) {
 						sw[p * ST + PW * my_piece + t] = tw[gg][t];
@@ -286,7 +291,7 @@ void s_accum_kernel(int64_t n_items, const int32_t *__restrict__ item_blk, const
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 		__builtin_amdgcn_wave_barrier();
 		// ---- every lane: its own pair out of LDS
-		if(q < end) {
+		if(mine) {
 			double w[BLK], u[BLK];
 #pragma unroll
 			for(int e = 0; e < BLK; ++ e) {
@@ -308,8 +313,8 @@ void s_accum_kernel(int64_t n_items, const int32_t *__restrict__ item_blk, const
 		__builtin_amdgcn_wave_barrier();
 	}
 	int nact = end - beg;
-	if(nact > 64)
-		nact = 64;
+	if(nact > RP)
+		nact = RP;
 	// in-order reduction through LDS in two halves of the block
 	double sum = 0;
 #pragma unroll
