@@ -514,10 +514,10 @@ static void schur_form_t(spp_ctx *ctx, const double *d_vals, const double *d_rhs
 	const int64_t *voff = sp.sparse_S ? sp.sblk_voff.p : nullptr;
 	double *xcol = sp.sparse_S ? S + sp.s_st.nvals : S + sp.n_red * ld; // reduced rhs
 	phase_begin(ctx, SPP_PHASE_SCHUR_INV);
-	// Every written block of S is ASSIGNED by the accumulation kernels. When the (dense, unsharded) reduced system
-	// has all of its upper blocks written, only the padding columns -- which carry the reduced rhs -- need
+	// Every written block of S is ASSIGNED by the accumulation kernels. When the (dense, unsharded) reduced system lives in
+	// the solver's own buffer (not a caller's: the split API hands S to an all-reduce) and has all of its upper blocks written, only the padding columns -- which carry the reduced rhs -- need
 	// clearing: nothing below the diagonal is ever an operand (220 MB memset -> 1 MB on the Venice shape).
-	if(!sp.sparse_S && ctx->shard_world == 1 && sp.n_sblk == sp.nc * (sp.nc + 1) / 2 && sp.n_red == sp.nc * DP)
+	if(S == sp.S.p && !sp.sparse_S && ctx->shard_world == 1 && sp.n_sblk == sp.nc * (sp.nc + 1) / 2 && sp.n_red == sp.nc * DP)
 		SPP_HIP_CHECK(hipMemsetAsync(S + sp.n_red * ld, 0, (size_t)(schur_buffer_doubles(ctx) - sp.n_red * ld) * sizeof(double), s));
 	else
 		SPP_HIP_CHECK(hipMemsetAsync(S, 0, (size_t)schur_buffer_doubles(ctx) * sizeof(double), s));
