@@ -70,6 +70,25 @@ def test_posv_matches_numpy(hip_ctx, n):
     assert np.linalg.norm(x - xr) / np.linalg.norm(xr) < 1e-11
 
 
+@pytest.mark.parametrize("n", [2688, 3072, 3201, 4224])
+def test_posv_large_sizes(hip_ctx, n):
+    """sizes that run the two-stream schedule with the mixed-granularity trailing update (whole 128 x 128 tiles +
+    64 x 64 quarters), its rectangular right-hand-side tile column (n a multiple of 128) and the hand-over to
+    the single-stream steps"""
+    A = _spd(n, 7 + n)
+    b = np.random.default_rng(n).standard_normal(n)
+    dA = api.DeviceArray.from_host(hip_ctx, np.asfortranarray(A).ravel(order="F"))
+    db = api.DeviceArray.from_host(hip_ctx, b)
+    st = hip_ctx._check(hip_ctx.lib.spp_dense_posv(hip_ctx.h, dA.ptr, n, n, db.ptr))
+    assert st == 0
+    x = db.download()
+    R = np.triu(dA.download().reshape((n, n), order="F"))
+    dA.free(); db.free()
+    xr = np.linalg.solve(A, b)
+    assert np.linalg.norm(x - xr) / np.linalg.norm(xr) < 1e-11
+    assert np.abs(R.T @ R - A).max() / np.abs(A).max() < 1e-13
+
+
 def test_potrf_reports_not_posdef(hip_ctx):
     """reference contract: non-positive pivot -> false (BlockMatrix.cpp:9765-9771)"""
     n = 200
