@@ -129,7 +129,8 @@ int spp_block_ordering(int64_t nb, const int64_t *col_ptr, const int64_t *row_id
 int spp_factor_solve(spp_ctx *ctx, const double *h_vals, double *h_rhs_inout);
 
 /* ---- numeric: device-resident entry points (Lambda lives in HBM across GN iterations) ------------
- * d_vals: nvals doubles in the layout given to spp_analyze; d_rhs: n doubles, in/out. */
+ * d_vals: nvals doubles in the layout given to spp_analyze; d_rhs: n doubles, in/out (contents unspecified after
+ * SPP_NOT_POSDEF: the status is fetched once, after the solves have run). */
 int spp_factor_solve_device(spp_ctx *ctx, const double *d_vals, double *d_rhs_inout);
 
 /* split form for multi-GPU: (1) each rank forms its partial Schur complement and

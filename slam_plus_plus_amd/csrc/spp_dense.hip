@@ -1271,6 +1271,16 @@ int dense_info_fetch(spp_ctx *ctx)
 	return h_info;
 }
 
+// factorization without the host round trip for the status: the caller enqueues what follows (solves, back-
+// substitution) and fetches the status with dense_info_fetch() at the end -- after a failed factorization
+// those kernels work on garbage, which is harmless (no data-dependent waits) and discarded by the caller
+void dense_potrf_upper_enqueue(spp_ctx *ctx, double *d_A, int64_t n, int64_t ld)
+{
+	SPP_REQUIRE(ld % NB == 0 && n < ld, SPP_E_BADARG, "dense_potrf_upper: ld must be a multiple of 128 and > n");
+	dense_info_reset(ctx);
+	dense_factor_steps(ctx, d_A, ld, n, n, n + 1, (n + NB - 1) / NB, true);
+}
+
 int dense_potrf_upper(spp_ctx *ctx, double *d_A, int64_t n, int64_t ld, bool /*keep_inverses*/)
 {
 	SPP_REQUIRE(ld % NB == 0 && n < ld, SPP_E_BADARG, "dense_potrf_upper: ld must be a multiple of 128 and > n");

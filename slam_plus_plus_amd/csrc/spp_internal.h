@@ -228,12 +228,14 @@ void schur_pack(spp_ctx *ctx, double *S, double *packed, bool pack);
 // ---- spp_dense.hip ----
 constexpr int DENSE_NB = 128;
 int dense_potrf_upper(spp_ctx *ctx, double *d_A, int64_t n, int64_t ld, bool keep_inverses);
+void dense_potrf_upper_enqueue(spp_ctx *ctx, double *d_A, int64_t n, int64_t ld);
+int dense_info_fetch(spp_ctx *ctx);
 void dense_potrs_upper(spp_ctx *ctx, const double *d_R, int64_t n, int64_t ld, double *d_b);
 void dense_factor_steps(spp_ctx *ctx, double *d_A, int64_t ld, int64_t n, int64_t rows, int64_t ncols,
 	int64_t nsteps, bool has_rhs);
 void dense_info_reset(spp_ctx *ctx);
 void dense_reserve(spp_ctx *ctx, int64_t nblk); // workspaces for nblk diagonal blocks (call at analyze time)
-int dense_info_fetch(spp_ctx *ctx);
+
 void dense_chain_check(spp_ctx *ctx); // call after the stream was synchronized
 void dense_set_padding(spp_ctx *ctx, double *d_A, int64_t ld, int64_t n);
 bool dense_gemm_tn_sub(spp_ctx *ctx, int64_t m, int64_t n, int64_t k, const double *A, int64_t lda,

@@ -563,10 +563,10 @@ static int schur_finish_t(spp_ctx *ctx, const double *d_vals, double *S, double 
 	} else {
 		phase_begin(ctx, SPP_PHASE_FACTOR);
 		dense_set_padding(ctx, S, ld, sp.n_red);
-		int ret = dense_potrf_upper(ctx, S, sp.n_red, ld, true);
+		// the status of the factorization is fetched at the very end: a host round trip here would leave the GPU
+		// idle for ~40 us before the solves (after a failure they run on garbage and the result is discarded)
+		dense_potrf_upper_enqueue(ctx, S, sp.n_red, ld);
 		phase_end(ctx, SPP_PHASE_FACTOR);
-		if(ret != SPP_OK)
-			return ret;
 		xcol = S + sp.n_red * ld;
 		phase_begin(ctx, SPP_PHASE_TRISOLVE);
 		dense_potrs_upper(ctx, S, sp.n_red, ld, xcol);
@@ -585,6 +585,8 @@ static int schur_finish_t(spp_ctx *ctx, const double *d_vals, double *S, double 
 			sp.nc, sp.pose_rbase.p, xcol, d_rhs);
 	phase_end(ctx, SPP_PHASE_BACKSUBST);
 	SPP_HIP_CHECK(hipGetLastError());
+	if(!sp.sparse_S && dense_info_fetch(ctx))
+		return SPP_NOT_POSDEF;
 	return SPP_OK;
 }
 

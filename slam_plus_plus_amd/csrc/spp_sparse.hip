@@ -1059,8 +1059,7 @@ int sparse_factor_solve(spp_ctx *ctx, const double *d_vals, double *d_rhs)
 	}
 	phase_end(ctx, SPP_PHASE_FACTOR);
 	SPP_HIP_CHECK(hipGetLastError());
-	if(dense_info_fetch(ctx))
-		return SPP_NOT_POSDEF;
+	// the status is fetched after the solves (no host round trip between factorization and solves)
 	phase_begin(ctx, SPP_PHASE_TRISOLVE);
 	hipLaunchKernelGGL(gather_perm_kernel, dim3(gn), dim3(256), 0, s, sp->n, sp->perm_scalar.p, d_rhs, sp->xperm.p);
 	for(int64_t l = 0; l < sp->n_levels; ++ l) {
@@ -1080,6 +1079,8 @@ int sparse_factor_solve(spp_ctx *ctx, const double *d_vals, double *d_rhs)
 	hipLaunchKernelGGL(scatter_perm_kernel, dim3(gn), dim3(256), 0, s, sp->n, sp->perm_scalar.p, sp->xperm.p, d_rhs);
 	phase_end(ctx, SPP_PHASE_TRISOLVE);
 	SPP_HIP_CHECK(hipGetLastError());
+	if(dense_info_fetch(ctx))
+		return SPP_NOT_POSDEF;
 	return SPP_OK;
 }
 
