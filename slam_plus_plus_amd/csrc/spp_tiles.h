@@ -26,6 +26,18 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane)
 	return u.d;
 }
 
+// broadcast of a double from a compile-time lane to ALL lanes, result in VGPRs (two ds_bpermute_b32 through the
+// LDS crossbar, no memory access): asynchronous (lgkmcnt), so it can be issued ahead of an MFMA and waited for in
+// its shadow -- unlike v_readlane, which writes SGPRs and stalls 70-100 cycles while the wave's MFMA is in flight
+__device__ __forceinline__ double bcast_f64(double v, int src_lane)
+{
+	union { double d; int i[2]; } u;
+	u.d = v;
+	u.i[0] = __builtin_amdgcn_ds_bpermute(src_lane << 2, u.i[0]);
+	u.i[1] = __builtin_amdgcn_ds_bpermute(src_lane << 2, u.i[1]);
+	return u.d;
+}
+
 // bit j of a per-lane mask as 0 / ~0 (v_bfe_i32), and a double AND-ed with such a word: VGPR-only masking
 __device__ __forceinline__ int sbit(unsigned mask, int j)
 {
@@ -157,8 +169,16 @@ __device__ __forceinline__ void diag_tile_factor_rt(const int TS, double *T, dou
 		const double aop = and_f64(-rowv * pinv, aw); // A[i][k]: -W[j][i] / p_j for rows i > j
 		const double bop = and_f64(rowv, bw);         // B[k][c]:  W[j][c], column j dropped
 		// scalars of the next pivot: W[j][j+1] and W[j+1][j+1] before this pivot's update
+#ifndef SPP_TILE_BPERMUTE
 		const double wj = readlane_f64(rowv, (j + 1) | (qj << 4));
 		const double wd = readlane_f64(diag, (j + 1) | (((j + 1) & 3) << 4));
+#else
+		// experiment: broadcast into VGPRs (ds_bpermute), issued before the MFMA and consumed in its shadow. Measured
+		// 5 700 instead of 5 400 cycles per tile: the crossbar round trip plus fma -> rcp -> Newton -> scale is longer
+		// than the MFMA it was meant to hide under. Kept for reference.
+		const double wj = bcast_f64(rowv, (j + 1) | (qj << 4));
+		const double wd = bcast_f64(diag, (j + 1) | (((j + 1) & 3) << 4));
+#endif
 		__builtin_amdgcn_sched_barrier(0);
 		acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
 		__builtin_amdgcn_sched_barrier(0);
