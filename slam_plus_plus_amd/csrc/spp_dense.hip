@@ -951,8 +951,8 @@ static void ensure_dense_work(spp_ctx *ctx, int64_t nblk)
 		if(!ctx->dense.aux)
 		SPP_HIP_CHECK(hipStreamCreateWithPriority(&ctx->dense.aux, hipStreamNonBlocking,
 			(e && !strcmp(e, "hi")) ? prio_hi : prio_lo));
-		// third stream (tile-row remainder, see dense_factor_steps_enqueue). Not CU-masked: a second masked stream
-		// beside the bulk stream doubled the factorization time (the two seem to share one hardware queue).
+		// third stream (tile-row remainder, see dense_factor_steps_enqueue). Not CU-masked: with a mask of "every CU
+		// but two" on it the factorization took twice as long (cause not established).
 		if(!ctx->dense.row)
 			SPP_HIP_CHECK(hipStreamCreateWithFlags(&ctx->dense.row, hipStreamNonBlocking));
 		SPP_HIP_CHECK(hipEventCreateWithFlags(&ctx->dense.ev_row, hipEventDisableTiming));
