@@ -293,11 +293,12 @@ static void launch_gemm(hipStream_t s, int64_t M, int64_t N, int K, const double
 // --------------------------------------------------------------------------------------------------
 constexpr int FS_KMAX = 128, FS_STRIDE = FS_KMAX + 2;
 
-template <int BM, int BN, int WM, int WN, int MODE>
+template <int BM, int BN, int WM, int WN, int MODE, int ATRI = 0>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64)
 void gemm_tn_staged_kernel(int64_t M, int64_t N, int K, const double *__restrict__ A, int64_t lda,
 	const double *B, int64_t ldb, double *C, int64_t ldc, int upper_only)
 {
+	constexpr bool a_upper_tri = ATRI != 0; // A(k, m) = 0 for k > m, BM covers all of A's columns (m0 == 0)
 	constexpr int NWM = BM / WM, NWN = BN / WN, NT = NWM * NWN * 64;
 	constexpr int TA = WM / 16, TB = WN / 16;
 	extern __shared__ double fs_lds[];
@@ -319,7 +320,8 @@ void gemm_tn_staged_kernel(int64_t M, int64_t N, int K, const double *__restrict
 			const int p = tid + i * NT, col = p / KP, q = p % KP;
 			int64_t gc = m0 + col;
 			if(gc > M - 1) gc = M - 1;
-			va[i] = *(const double2*)(A + gc * lda + 2 * q);
+			// a_upper_tri: A(k, m) = 0 for k > m (the inverse of a diagonal block): the zero half is not fetched
+			va[i] = (a_upper_tri && 2 * q > gc) ? make_double2(0, 0) : *(const double2*)(A + gc * lda + 2 * q);
 		}
 #pragma unroll
 		for(int i = 0; i < PB; ++ i) {
@@ -356,8 +358,10 @@ void gemm_tn_staged_kernel(int64_t M, int64_t N, int K, const double *__restrict
 			}
 		}
 	__syncthreads();
+	// rows wm .. wm + WM - 1 of an upper triangular A^T only see k < wm + WM (wave-uniform bound)
+	const int kend = (a_upper_tri && wm + WM < FS_KMAX) ? wm + WM : FS_KMAX; // compile-time FS_KMAX unless ATRI
 #pragma unroll 4
-	for(int k4 = 0; k4 < FS_KMAX; k4 += 4) {
+	for(int k4 = 0; k4 < kend; k4 += 4) {
 		double fa[TA], fb[TB];
 #pragma unroll
 		for(int a = 0; a < TA; ++ a)
@@ -385,14 +389,14 @@ void gemm_tn_staged_kernel(int64_t M, int64_t N, int K, const double *__restrict
 		}
 }
 
-template <int BM, int BN, int WM, int WN, int MODE>
+template <int BM, int BN, int WM, int WN, int MODE, int ATRI = 0>
 static void launch_gemm_staged(hipStream_t s, int64_t M, int64_t N, int K, const double *A, int64_t lda,
 	const double *B, int64_t ldb, double *C, int64_t ldc, bool upper_only)
 {
 	static bool attr = false;
 	const size_t lds = (size_t)(BM + BN) * FS_STRIDE * sizeof(double);
 	if(!attr) {
-		SPP_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tn_staged_kernel<BM, BN, WM, WN, MODE>,
+		SPP_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tn_staged_kernel<BM, BN, WM, WN, MODE, ATRI>,
 			hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 		attr = true;
 	}
@@ -401,7 +405,8 @@ static void launch_gemm_staged(hipStream_t s, int64_t M, int64_t N, int K, const
 	dim3 block((BM / WM) * (BN / WN) * 64);
 	if(!grid.x || !grid.y)
 		return;
-	hipLaunchKernelGGL((gemm_tn_staged_kernel<BM, BN, WM, WN, MODE>), grid, block, lds, s,
+	SPP_REQUIRE(!ATRI || M <= BM, SPP_E_BADARG, "staged gemm: a triangular A needs one tile row");
+	hipLaunchKernelGGL((gemm_tn_staged_kernel<BM, BN, WM, WN, MODE, ATRI>), grid, block, lds, s,
 		M, N, K, A, lda, B, ldb, C, ldc, upper_only ? 1 : 0);
 }
 
@@ -1051,6 +1056,13 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 		const char *e = getenv("SPP_WAIT_MID_BELOW");
 		wait_mid_below = e ? atol(e) : 0;
 	}
+	static int panel_waves = -1, panel_tri = 0;
+	if(panel_waves < 0) {
+		const char *e = getenv("SPP_PANEL_WAVES"); // 4: two MFMA tiles per wave, 8: one
+		panel_waves = e ? atoi(e) : 8;
+		e = getenv("SPP_PANEL_TRI"); // skip the zero half of the triangular inverse: measured 1.5 % SLOWER (conditional loads, run-time loop bound)
+		panel_tri = e ? atoi(e) : 0;
+	}
 	bool row_pending = false; // the remainder of tile row k (stream ctx->dense.row) has to finish before panel k
 	auto potrf_and_panel = [&](hipStream_t st, int64_t k) {
 		const int64_t k0 = k * NB;
@@ -1077,6 +1089,13 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 				launch_gemm<128, 32, 32, 32, 1>(st, NB, ncols - c1, NB, tinv, NB, d_A + k0 + c1 * ld, ld,
 					d_A + k0 + c1 * ld, ld, false);
 			else
+				if(panel_waves == 8 && panel_tri) // one MFMA tile per wave; the inverse is upper triangular: half of it is neither fetched nor multiplied
+					launch_gemm_staged<128, 16, 16, 16, 1, 1>(st, NB, ncols - c1, NB, tinv, NB, d_A + k0 + c1 * ld, ld,
+						d_A + k0 + c1 * ld, ld, false);
+				else if(panel_waves == 8)
+					launch_gemm_staged<128, 16, 16, 16, 1>(st, NB, ncols - c1, NB, tinv, NB, d_A + k0 + c1 * ld, ld,
+						d_A + k0 + c1 * ld, ld, false);
+				else
 				launch_gemm_staged<128, 16, 32, 16, 1>(st, NB, ncols - c1, NB, tinv, NB, d_A + k0 + c1 * ld, ld,
 					d_A + k0 + c1 * ld, ld, false);
 		}
