@@ -152,7 +152,10 @@ def main():
     barrier_sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        t1 = time.perf_counter()
         solve()
+        if os.environ.get("BENCH_DEBUG"):
+            print("step %.3f ms" % (1e3 * (time.perf_counter() - t1)), file=sys.stderr)
     ctx.synchronize()
     barrier_sync()
     dt = time.perf_counter() - t0
@@ -256,7 +259,10 @@ def main():
         ctx.synchronize()
         t0 = time.perf_counter()
         for _ in range(gn_steps):
+            t1 = time.perf_counter()
             dxn = gn_resident()
+            if os.environ.get("BENCH_DEBUG"):
+                print("resident iteration %.3f ms" % (1e3 * (time.perf_counter() - t1)), file=sys.stderr)
         ctx.synchronize()
         dt_res = time.perf_counter() - t0
         # the linearization kernel alone (hipEvent-free: wall clock around a synchronized burst)
