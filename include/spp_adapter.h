@@ -13,8 +13,9 @@
  *   bool SymbolicDecomposition_Blocky(const CUberBlockMatrix &lambda);
  *   bool Solve_PosDef_Blocky(const CUberBlockMatrix &lambda, Eigen::VectorXd &eta);
  *   bool Factorize_PosDef_Blocky(...)   -- only used by the L / FastL nonlinear solvers
- *       (NonlinearSolver_FastL.h:2131,2388); delegated to the reference's CLinearSolver_CSparse,
- *       which is outside of the accelerated path.
+ *       (NonlinearSolver_FastL.h:2131,2388); outside of the accelerated path: supplied by
+ *       the shim class include/shim/slam/LinearSolver_UberBlock.h, which delegates to the reference's
+ *       own implementation.
  * Error contract: false = not positive definite (the caller prints "Cholesky failed" and stops,
  * NonlinearSolver_Lambda.h:628-664); std::bad_alloc for SPP_E_NOMEM; std::runtime_error otherwise
  * (as LinearSolver_Schur_GPU.cpp:734-797 does for CUDA/CULA errors).
@@ -113,7 +114,10 @@ public:
 			if(!SymbolicDecomposition_Blocky(r_lambda))
 				return false;
 		}
-		Flatten_Values(r_lambda);
+		if(!Flatten_Values(r_lambda)) { // same counts, different structure: the stored symbolic decomposition is stale
+			if(!SymbolicDecomposition_Blocky(r_lambda) || !Flatten_Values(r_lambda))
+				throw std::runtime_error("libspp_hip adapter: the block structure of lambda changed while it was flattened");
+		}
 		int n_result = Check(spp_factor_solve(m_p_ctx, &m_vals[0], r_eta.data()));
 		return n_result == SPP_OK; // SPP_NOT_POSDEF leaves eta untouched, like the reference
 	}
@@ -124,18 +128,6 @@ public:
 		return Solve_PosDef_Blocky(r_lambda, r_eta);
 	}
 
-#ifdef __LINEAR_SOLVER_CS_INCLUDED_ORIGINAL
-	/** only the L / FastL solvers call this; outside of the accelerated path */
-	bool Factorize_PosDef_Blocky(CUberBlockMatrix &r_factor, const CUberBlockMatrix &r_lambda,
-		std::vector<size_t> &r_workspace, size_t n_dest_row_id = 0,
-		size_t n_dest_column_id = 0, bool b_upper_factor = true)
-	{
-		return m_fallback_factorizer.Factorize_PosDef_Blocky(r_factor, r_lambda, r_workspace,
-			n_dest_row_id, n_dest_column_id, b_upper_factor);
-	}
-protected:
-	CLinearSolver_CSparse_Original m_fallback_factorizer;
-#endif // __LINEAR_SOLVER_CS_INCLUDED_ORIGINAL
 
 protected:
 	inline void Require_Context()
@@ -196,20 +188,37 @@ protected:
 		m_n_sym_blocks = m_row_idx.size();
 	}
 
-	void Flatten_Values(const CUberBlockMatrix &r_lambda)
+	/**
+	 *	@brief copies the block values; returns false (nothing is trusted then) when the structure of
+	 *		r_lambda is not the one of the last symbolic decomposition -- same block counts but other block
+	 *		rows or sizes, e.g. one edge replaced by another: the caller re-analyzes and flattens again
+	 */
+	bool Flatten_Values(const CUberBlockMatrix &r_lambda)
 	{
 		size_t n_blk = 0;
-		for(size_t i = 0, n = r_lambda.n_BlockColumn_Num(); i < n; ++ i) {
+		const size_t n = r_lambda.n_BlockColumn_Num();
+		if(n != m_dim.size())
+			return false;
+		for(size_t i = 0; i < n; ++ i) {
+			if(int32_t(r_lambda.n_BlockColumn_Column_Num(i)) != m_dim[i])
+				return false;
 			for(size_t j = 0, m = r_lambda.n_BlockColumn_Block_Num(i); j < m; ++ j) {
 				size_t n_row = r_lambda.n_Block_Row(i, j);
 				if(n_row > i)
 					continue;
+				if(n_blk >= m_row_idx.size() || int64_t(n_blk) >= m_col_ptr[i + 1] || m_row_idx[n_blk] != int64_t(n_row))
+					return false;
 				CUberBlockMatrix::_TyConstMatrixXdRef t_block = r_lambda.t_Block_AtColumn(i, j);
+				if(int32_t(t_block.rows()) != m_dim[n_row] || int32_t(t_block.cols()) != m_dim[i])
+					return false;
 				memcpy(&m_vals[size_t(m_blk_off[n_blk])], t_block.data(),
 					size_t(t_block.rows()) * size_t(t_block.cols()) * sizeof(double)); // column-major dense block
 				++ n_blk;
 			}
+			if(int64_t(n_blk) != m_col_ptr[i + 1])
+				return false;
 		}
+		return true;
 	}
 };
 

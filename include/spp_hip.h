@@ -155,7 +155,9 @@ int spp_schur_unpack(spp_ctx *ctx, const double *d_packed, double *d_S_rhs);
  * One homogeneous binary-edge group: residual dimension rd, vertex 0 width d0, vertex 1 width d1.
  * J0: ne x (rd x d0) col-major, J1: ne x (rd x d1), Omega: ne x (rd x rd), r: ne x rd.
  * The unary factor (identity, FlatSystem.h:441,467) is added to the diagonal block of vertex
- * `unary_vertex` (pass -1 for none); `damping` is added to every diagonal entry of Lambda
+ * `unary_vertex` (pass -1 for none). The reference's default build puts it on vertex 0 whatever its type
+ * (__AUTO_UNARY_FACTOR_ON_VERTEX_ZERO, FlatSystem.h:331-337, _Lambda_Base.h:1903-1924; without that macro: on the
+ * first vertex of the first edge). `damping` is added to every diagonal entry of Lambda
  * (Levenberg-Marquardt, NonlinearSolver_Lambda_LM.h:228-239; 0 for Gauss-Newton). */
 int spp_assemble_analyze(spp_ctx *ctx, int64_t nv, const int32_t *h_dim,
 	int64_t ne, const int64_t *h_v0, const int64_t *h_v1, int d0, int d1, int rd,

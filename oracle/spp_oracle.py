@@ -121,7 +121,7 @@ def assemble(prob, damping=None):
     dst = np.concatenate([eblk, dblk[prob.v0], dblk[prob.v1]])
     soff = np.concatenate([e * d0 * d1, o00 + e * d0 * d0, o11 + e * d1 * d1])
     seq = np.concatenate([3 * e, 3 * e + 1, 3 * e + 2])
-    if prob.unary_vertex >= 0:  # added after all edges (_Lambda_Base.h:1903-1924)
+    if prob.unary_vertex >= 0:  # added after all edges (_Lambda_Base.h:1903-1924; vertex 0 in the default build, FlatSystem.h:337)
         dst = np.append(dst, dblk[prob.unary_vertex])
         soff = np.append(soff, ouf)
         seq = np.append(seq, 3 * ne)

@@ -133,6 +133,8 @@ int spp_free_memory(spp_ctx *ctx)
 	ctx->geom_partial.release();
 	ctx->dense.flags.release();
 	ctx->dense.epoch = 0;
+	ctx->dense.sync.release();
+	ctx->dense.sync_epoch = 0;
 	ctx->d_vals.release();
 	ctx->d_rhs.release();
 	ctx->mode = -1;

@@ -293,6 +293,51 @@ static void launch_gemm(hipStream_t s, int64_t M, int64_t N, int K, const double
 // --------------------------------------------------------------------------------------------------
 constexpr int FS_KMAX = 128, FS_STRIDE = FS_KMAX + 2;
 
+// ---- cross-stream hand-offs through words in device memory ------------------------------------------
+// A flag holds the epoch of the factorization that last completed a piece of work. Signalling is a
+// one-wave kernel BEHIND the producing kernel on the producer's stream, waiting a one-wave kernel IN FRONT
+// of the consumer on its stream: the kernel boundaries are the release and the acquire (no fences inside the
+// compute kernels), and a waiter holds one wave slot, never the slots the producer still needs (a consumer
+// that polled in its own prologue would park hundreds of workgroups on the CUs of the kernel it waits for).
+// Every wait is bounded: on a timeout (100 MHz wall clock) the abort word is set, all later waits fall
+// through and the host reports the failure.
+struct FlagWait {
+	const int *flag; // nullptr: no wait
+	int value;
+	int *abort;
+	long long timeout_ticks;
+};
+
+__device__ __forceinline__ void flag_spin(const FlagWait &fw)
+{
+	const long long t0 = wall_clock64();
+	for(int it = 0;; ++ it) {
+		if(__hip_atomic_load(fw.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == fw.value)
+			return;
+		if((it & 15) == 15) {
+			if(__hip_atomic_load(fw.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+				return;
+			if(wall_clock64() - t0 > fw.timeout_ticks) {
+				__hip_atomic_store(fw.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				return;
+			}
+		}
+		__builtin_amdgcn_s_sleep(2);
+	}
+}
+
+__global__ void flag_signal_kernel(int *flag, int value)
+{
+	if(threadIdx.x == 0)
+		__hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void flag_wait_kernel(FlagWait fw)
+{
+	if(threadIdx.x == 0)
+		flag_spin(fw);
+}
+
 template <int BM, int BN, int WM, int WN, int MODE, int ATRI = 0>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64)
 void gemm_tn_staged_kernel(int64_t M, int64_t N, int K, const double *__restrict__ A, int64_t lda,
@@ -924,9 +969,19 @@ void dense_set_padding(spp_ctx *ctx, double *d_A, int64_t ld, int64_t n)
 // --------------------------------------------------------------------------------------------------
 // host drivers
 // --------------------------------------------------------------------------------------------------
+// info[0]: first failing pivot + 1, info[1]: timeout of the backward-substitution chain, info[2]: abort flag of
+// the device-flag hand-offs (stays set until the host has seen it) -- zeroed once, when the buffer is created
+static void ensure_info(spp_ctx *ctx)
+{
+	if(!ctx->dense.info.p) {
+		ctx->dense.info.reserve(4);
+		SPP_HIP_CHECK(hipMemsetAsync(ctx->dense.info.p, 0, 4 * sizeof(int), ctx->stream));
+	}
+}
+
 static void ensure_dense_work(spp_ctx *ctx, int64_t nblk)
 {
-	ctx->dense.info.reserve(4);
+	ensure_info(ctx);
 	ctx->dense.tinv_all.reserve((size_t)nblk * NB * NB);
 	ctx->dense.xtmp.reserve((size_t)(nblk + 1) * NB);
 	if(!ctx->dense.aux) {
@@ -987,7 +1042,8 @@ static void ensure_dense_work(spp_ctx *ctx, int64_t nblk)
 //   ncols  columns carried along (rows + 1 with a rhs column)
 // Does not synchronize; failures are recorded in ctx->dense.info (first failing pivot + 1).
 static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, int64_t n, int64_t rows, int64_t ncols,
-	int64_t nsteps, bool has_rhs);
+	int64_t nsteps, bool has_rhs, bool use_flags = false);
+static bool flag_schedule_usable(spp_ctx *ctx);
 
 // Optional (SPP_DENSE_GRAPH=1): the two-stream schedule of one factorization is captured into a hipGraph
 // the second time the same (buffer, shape) is factored and replayed afterwards -- the kernel arguments
@@ -1003,6 +1059,10 @@ void dense_factor_steps(spp_ctx *ctx, double *d_A, int64_t ld, int64_t n, int64_
 		use_graph = e ? atoi(e) : 0;
 	}
 	DenseWork &dw = ctx->dense;
+	if(nsteps >= 4 && flag_schedule_usable(ctx)) { // cross-stream hand-offs through device flags instead of events
+		dense_factor_steps_enqueue(ctx, d_A, ld, n, rows, ncols, nsteps, has_rhs, true);
+		return;
+	}
 	if(!use_graph || (ctx->flags & SPP_FLAG_PROFILE) || nsteps < 4) {
 		dense_factor_steps_enqueue(ctx, d_A, ld, n, rows, ncols, nsteps, has_rhs);
 		return;
@@ -1037,11 +1097,130 @@ void dense_factor_steps(spp_ctx *ctx, double *d_A, int64_t ld, int64_t n, int64_
 	dense_factor_steps_enqueue(ctx, d_A, ld, n, rows, ncols, nsteps, has_rhs);
 }
 
+static void flag_signal(hipStream_t st, int *flag, int value)
+{
+	hipLaunchKernelGGL(flag_signal_kernel, dim3(1), dim3(64), 0, st, flag, value);
+}
+
+static FlagWait make_flag_wait(spp_ctx *ctx, const int *flag, int value, double timeout_ms = 500.0)
+{
+	return FlagWait{flag, value, ctx->dense.info.p + 2, (long long)(timeout_ms * 1e5)};
+}
+
+static void flag_wait(spp_ctx *ctx, hipStream_t st, const int *flag, int value, double timeout_ms = 500.0)
+{
+	hipLaunchKernelGGL(flag_wait_kernel, dim3(1), dim3(64), 0, st, make_flag_wait(ctx, flag, value, timeout_ms));
+}
+
+// Do the chain stream and the bulk stream run concurrently? Both directions are tried with the WAIT ENQUEUED
+// FIRST: two streams that share a hardware queue would make a waiter block its own signaller; such a pair times
+// out here (20 ms) and the event schedule stays in use for this ctx stream.
+static bool flag_schedule_selftest(spp_ctx *ctx)
+{
+	DenseWork &dw = ctx->dense;
+	hipStream_t st[2] = {ctx->stream, dw.aux};
+	dw.sync.reserve(16);
+	SPP_HIP_CHECK(hipMemsetAsync(dw.sync.p, 0, 16 * sizeof(int), ctx->stream));
+	SPP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	for(int p = 0; p < 2; ++ p) {
+		flag_wait(ctx, st[p], dw.sync.p + p, 1, 20.0);
+		flag_signal(st[1 - p], dw.sync.p + p, 1);
+	}
+	for(int i = 0; i < 2; ++ i)
+		SPP_HIP_CHECK(hipStreamSynchronize(st[i]));
+	int h_abort = 0;
+	SPP_HIP_CHECK(hipMemcpy(&h_abort, dw.info.p + 2, sizeof(int), hipMemcpyDeviceToHost));
+	if(h_abort) {
+		SPP_HIP_CHECK(hipMemset(dw.info.p + 2, 0, sizeof(int)));
+		return false;
+	}
+	return true;
+}
+
+static bool flag_schedule_usable(spp_ctx *ctx)
+{
+	static int sched = -1;
+	if(sched < 0) {
+		const char *e = getenv("SPP_DENSE_SCHED"); // 0: cross-stream events (round 1), 1: device flags
+		sched = e ? atoi(e) : 1;
+	}
+	if(!sched)
+		return false;
+	DenseWork &dw = ctx->dense;
+	if(dw.sync_state == 0 || dw.sync_stream != ctx->stream) {
+		hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+		if(hipStreamIsCapturing(ctx->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone)
+			return false; // no self-test (host synchronization) inside a capture
+		dw.sync_state = flag_schedule_selftest(ctx) ? 1 : -1;
+		dw.sync_stream = ctx->stream;
+	}
+	return dw.sync_state == 1;
+}
+
 static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, int64_t n, int64_t rows, int64_t ncols,
-	int64_t nsteps, bool has_rhs)
+	int64_t nsteps, bool has_rhs, bool use_flags)
 {
 	hipStream_t s = ctx->stream, s2 = ctx->dense.aux;
 	hipEvent_t evA = ctx->dense.ev[0], evB = ctx->dense.ev[1];
+	// Hand-offs between the chain stream and the bulk stream: events (two barrier packets per direction, ~6 us
+	// each on the critical chain) or, with use_flags, words in device memory: flag[2 k] = "row panel k is
+	// complete" (signal kernel behind the panel solve on s, wait kernel in front of the bulk update on s2),
+	// flag[2 k + 1] = "bulk update k is complete" (signal kernel behind it on s2; the tile-row kernel of the
+	// chain polls it in its own prologue). Values are the epoch of this factorization.
+	DenseWork &dw = ctx->dense;
+	int ep = 0;
+	int64_t step_a = -1, step_b = -1; // steps whose hand-over / bulk update the "events" currently name
+	int64_t need_wait_b = -1;         // flags only: the next chain kernel has to wait for bulk update need_wait_b
+	if(use_flags) {
+		if(dw.sync.cap < (size_t)(2 * nsteps + 16)) {
+			dw.sync.reserve((size_t)(2 * nsteps + 16));
+			SPP_HIP_CHECK(hipMemsetAsync(dw.sync.p, 0, dw.sync.cap * sizeof(int), s));
+			dw.sync_epoch = 1; // the self-test used the value 1
+		}
+		ep = ++ dw.sync_epoch;
+		// the bulk stream must not see flags of this epoch... it cannot: they are set by kernels enqueued below.
+		// It must start after everything enqueued on the ctx stream so far (the matrix itself): one event per factorization
+		SPP_HIP_CHECK(hipEventRecord(evA, s));
+		SPP_HIP_CHECK(hipStreamWaitEvent(s2, evA, 0));
+	}
+	auto record_a = [&](int64_t k) { // row panel k is complete on s
+		step_a = k;
+		if(use_flags)
+			flag_signal(s, dw.sync.p + 2 * k, ep);
+		else
+			SPP_HIP_CHECK(hipEventRecord(evA, s));
+	};
+	auto wait_a_on_bulk = [&]() {
+		if(use_flags)
+			flag_wait(ctx, s2, dw.sync.p + 2 * step_a, ep);
+		else
+			SPP_HIP_CHECK(hipStreamWaitEvent(s2, evA, 0));
+	};
+	auto record_b = [&](int64_t k) { // bulk update k is complete on s2
+		step_b = k;
+		if(use_flags)
+			flag_signal(s2, dw.sync.p + 2 * k + 1, ep);
+		else
+			SPP_HIP_CHECK(hipEventRecord(evB, s2));
+	};
+	auto wait_b_kernel = [&](hipStream_t st) { // a wait of its own (event or one-wave kernel)
+		if(use_flags)
+			flag_wait(ctx, st, dw.sync.p + 2 * step_b + 1, ep);
+		else
+			SPP_HIP_CHECK(hipStreamWaitEvent(st, evB, 0));
+	};
+	auto wait_b_deferred = [&]() { // the chain's next tile-row kernel waits in its prologue (flags), or an event wait now
+		if(use_flags)
+			need_wait_b = step_b;
+		else
+			SPP_HIP_CHECK(hipStreamWaitEvent(s, evB, 0));
+	};
+	auto flush_wait_b = [&]() { // no tile-row kernel took the deferred wait: a wait kernel does
+		if(need_wait_b >= 0) {
+			flag_wait(ctx, s, dw.sync.p + 2 * need_wait_b + 1, ep);
+			need_wait_b = -1;
+		}
+	};
 	static int64_t trsm_shared_above = -1;
 	if(trsm_shared_above < 0) {
 		const char *e = getenv("SPP_TRSM_SHARED_ABOVE");
@@ -1076,7 +1255,7 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 		}
 		const int64_t c1 = k0 + NB;
 		if(bulk_pending && rows - c1 < wait_mid_below) {
-			SPP_HIP_CHECK(hipStreamWaitEvent(st, evB, 0));
+			wait_b_kernel(st);
 			bulk_pending = false;
 		}
 		if(c1 < ncols) { // panel: R_kj = Tinv^T S_kj in place (A = tinv: 128 x 128; B = C = S[k0.., c1..])
@@ -1119,6 +1298,7 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 			return;
 		for(int q = 0; q < npan; ++ q) {
 			const double *P = d_A + (kp0 + q * NB) + r0 * ld;
+			flush_wait_b();
 			// Under a running bulk update every wave slot of the chip is taken and a tile-row workgroup only
 			// starts where a bulk workgroup has just left: the fully staged kernel (66 KB of LDS) fits once
 			// into such a hole, the slab-pipelined one (18 KB, one wave per SIMD) four times.
@@ -1173,7 +1353,7 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 			break;
 		if(rows - c1 <= single_below) {
 			if(bulk_pending) {
-				SPP_HIP_CHECK(hipStreamWaitEvent(s, evB, 0));
+				wait_b_kernel(s);
 				bulk_pending = false;
 			}
 			const double *P = d_A + k0 + c1 * ld;
@@ -1199,19 +1379,20 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 		// stream BEFORE the tile row, so that consecutive bulk updates run back to back.
 		const bool early = (npan == 1) && eva_early && rows - c1 > early_above;
 		if(early)
-			SPP_HIP_CHECK(hipEventRecord(evA, s));
+			record_a(k);
 		// the bulk update of the previous pair touched every row >= c1 (evB still names that update:
 		// this wait is issued before the next record)
 		if(bulk_pending) {
-			SPP_HIP_CHECK(hipStreamWaitEvent(s, evB, 0));
+			wait_b_deferred();
 			if(early && split_row) // the third stream updates row k+1 as well; evB is re-recorded below
-				SPP_HIP_CHECK(hipStreamWaitEvent(ctx->dense.row, evB, 0));
+				wait_b_kernel(ctx->dense.row);
 			bulk_pending = false;
 		}
 		const int64_t cb = (npan == 2) ? c3 : c2;
 		const bool have_bulk = rows - cb > 0 && cb < ncols;
 		if(!early || !have_bulk) {
 			tile_row(c1, k0, 1);
+			flush_wait_b();
 			if(npan == 2) {
 				potrf_and_panel(s, k + 1);
 				tile_row(c2, k0, 2);
@@ -1220,8 +1401,8 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 		// bulk: rows [cb, rows) x cols [cb, ncols) -= P^T P with P = rows [k0, k0 + 128 npan)
 		if(have_bulk) {
 			if(!early)
-				SPP_HIP_CHECK(hipEventRecord(evA, s)); // both panels (and the tile rows) are complete here
-			SPP_HIP_CHECK(hipStreamWaitEvent(s2, evA, 0));
+				record_a(k); // both panels (and the tile rows) are complete here
+			wait_a_on_bulk();
 			const double *P = d_A + k0 + cb * ld;
 			hipStream_t keep = ctx->stream;
 			ctx->stream = s2; // dom events + gemm launch on the bulk stream
@@ -1233,11 +1414,12 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 			if(big)
 				dom_end(ctx, 2.0 * NB * npan * (0.5 * mr * (mr + 1.0) + mr * (double)(ncols - rows)));
 			ctx->stream = keep;
-			SPP_HIP_CHECK(hipEventRecord(evB, s2));
+			record_b(k);
 			bulk_pending = true;
 			if(early) {
 				const int64_t m = std::min<int64_t>(NB, rows - c1);
 				if(split_row && m == NB && ncols - c2 > 0) {
+					flush_wait_b();
 					// potrf_diag(k+1) needs the diagonal tile of row k+1 only; the rest of the row is needed by the
 					// panel solve AFTER it and is updated beside potrf_diag on the third stream
 					hipStream_t s3 = ctx->dense.row;
@@ -1251,13 +1433,19 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 					tile_row(c1, k0, 1);
 			}
 		}
+		flush_wait_b();
 		// next pair's first diagonal block + row panel overlaps the bulk update
 		if(k + npan < nsteps)
 			potrf_and_panel(s, k + npan);
 		k += npan;
 	}
-	if(bulk_pending)
-		SPP_HIP_CHECK(hipStreamWaitEvent(s, evB, 0));
+	if(bulk_pending) {
+		if(use_flags) { // the join is an event: the ctx stream's successors need the whole bulk stream drained
+			SPP_HIP_CHECK(hipEventRecord(evB, s2));
+			SPP_HIP_CHECK(hipStreamWaitEvent(s, evB, 0));
+		} else
+			SPP_HIP_CHECK(hipStreamWaitEvent(s, evB, 0));
+	}
 	if(row_pending)
 		SPP_HIP_CHECK(hipStreamWaitEvent(s, ctx->dense.ev_row, 0));
 	SPP_HIP_CHECK(hipGetLastError());
@@ -1270,7 +1458,7 @@ void dense_reserve(spp_ctx *ctx, int64_t nblk)
 
 void dense_info_reset(spp_ctx *ctx)
 {
-	ctx->dense.info.reserve(4);
+	ensure_info(ctx);
 	hipLaunchKernelGGL(set_info_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->dense.info.p);
 }
 
@@ -1284,10 +1472,16 @@ void dense_chain_check(spp_ctx *ctx)
 
 int dense_info_fetch(spp_ctx *ctx)
 {
-	int h_info = 0;
-	SPP_HIP_CHECK(hipMemcpyAsync(&h_info, ctx->dense.info.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+	int h_info[3] = {0, 0, 0};
+	SPP_HIP_CHECK(hipMemcpyAsync(h_info, ctx->dense.info.p, 3 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
 	SPP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-	return h_info;
+	if(h_info[2]) { // a cross-stream flag wait timed out: the result is garbage, the flag hand-offs stay off
+		SPP_HIP_CHECK(hipMemset(ctx->dense.info.p + 2, 0, sizeof(int)));
+		ctx->dense.sync_state = -1;
+		throw Error(SPP_E_HIP, "dense factorization: a cross-stream flag wait timed out (streams not concurrent?); "
+			"the following calls use the event schedule");
+	}
+	return h_info[0];
 }
 
 // factorization without the host round trip for the status: the caller enqueues what follows (solves, back-

@@ -142,6 +142,12 @@ struct DenseWork {
 	hipEvent_t ev[2] = {nullptr, nullptr};
 	hipStream_t row = nullptr;     // third stream: the part of tile row k+1 that only the NEXT panel solve needs
 	hipEvent_t ev_row = nullptr;
+	// device-flag hand-offs between the chain stream and the bulk stream (dense_factor_steps_enqueue):
+	// sync[2 k] = row panel k complete, sync[2 k + 1] = bulk update k complete, as the epoch of the factorization
+	DevBuf<int> sync;
+	int sync_epoch = 0;
+	int sync_state = 0;            // 0: not tested on this stream, 1: the streams run concurrently, -1: disabled
+	hipStream_t sync_stream = nullptr; // the ctx stream the self-test ran against
 };
 
 // ------------------------------------------------------------------------------------------------

@@ -166,6 +166,94 @@ def save_se2_graph(path, poses, edges, info):
             f.write(" ".join("%.17g" % x for x in m[iu]) + "\n")
 
 
+def save_se3_graph(path, edges, info, poses=None):
+    """3D pose graph in the reference's text format. edges: (m, 8) i j tx ty tz ax ay az (relative pose,
+    rotation as axis-angle) written as `EDGE3:AXISANGLE` (ParsePrimitives.h:556-617: the measurement is taken
+    as it stands, no roll-pitch-yaw conversion), info: (m, 6, 6) -> its 21 upper-triangular values row by row.
+    poses (n, 6) [t | roll pitch yaw] are optional `VERTEX3` lines (:741-797, RPY as the parser expects);
+    without them the reference initializes every pose by composing the edges, as it does for sphere2500."""
+    iu = np.triu_indices(6)
+    with open(path, "w") as f:
+        if poses is not None:
+            for i, p in enumerate(poses):
+                f.write("VERTEX3 %d " % i + " ".join("%.17g" % x for x in p) + "\n")
+        for e, m in zip(edges, info):
+            f.write("EDGE3:AXISANGLE %d %d " % (int(e[0]), int(e[1])) + " ".join("%.17g" % x for x in e[2:8]) + " ")
+            f.write(" ".join("%.17g" % x for x in np.asarray(m)[iu]) + "\n")
+
+
+def save_ba_graph(path, cams, intr, points, obs, info=None, cam_id=None, pt_id=None):
+    """Bundle adjustment graph in the reference's text format (data/Readme.txt, ParsePrimitives.h:861-931,
+    805-850, 1123-1184): `VERTEX_CAM id x y z qx qy qz qw fx fy cx cy d` stores the camera-to-world pose (centre
+    + quaternion), which the parser inverts into the world-to-camera [R | t] it optimizes; `VERTEX_XYZ id x y z`;
+    `EDGE_PROJECT_P2MC point-id cam-id u v xx xy yy`.
+      cams (nc, 6) world-to-camera [t | axis-angle] (the reference's internal CVertexCam state), intr (nc, 5)
+      fx fy cx cy d, points (np, 3), obs (no, 4) point index, camera index, u, v; info (no, 2, 2) or None (identity);
+      cam_id / pt_id: vertex ids (default: cameras 0..nc-1, points nc..nc+np-1)."""
+    from scipy.spatial.transform import Rotation
+    cams, intr, points, obs = (np.asarray(a, dtype=np.float64) for a in (cams, intr, points, obs))
+    nc, npts = cams.shape[0], points.shape[0]
+    cam_id = np.arange(nc) if cam_id is None else np.asarray(cam_id)
+    pt_id = nc + np.arange(npts) if pt_id is None else np.asarray(pt_id)
+    R = Rotation.from_rotvec(cams[:, 3:6])
+    C = -R.inv().apply(cams[:, :3])            # camera centre in the world
+    q = R.inv().as_quat()                       # x y z w, camera-to-world
+    order = np.argsort(np.concatenate([cam_id, pt_id]), kind="stable")
+    with open(path, "w") as f:
+        for v in order:                         # vertices in id order, as the incremental datasets have them
+            if v < nc:
+                f.write("VERTEX_CAM %d " % cam_id[v] + " ".join("%.17g" % x for x in (*C[v], *q[v], *intr[v])) + "\n")
+            else:
+                f.write("VERTEX_XYZ %d " % pt_id[v - nc] + " ".join("%.17g" % x for x in points[v - nc]) + "\n")
+        for k, o in enumerate(obs):
+            m = np.eye(2) if info is None else np.asarray(info[k])
+            f.write("EDGE_PROJECT_P2MC %d %d %.17g %.17g %.17g %.17g %.17g\n" % (
+                pt_id[int(o[0])], cam_id[int(o[1])], o[2], o[3], m[0, 0], m[0, 1], m[1, 1]))
+
+
+def load_bal(path):
+    """Bundle Adjustment in the Large problem file: `ncams npoints nobs`, nobs lines `cam point x y`, then 9
+    numbers per camera (Rodrigues vector, translation, f, k1, k2) and 3 per point. Returns dict(cam_index,
+    point_index, xy (nobs, 2), cameras (ncams, 9), points (npoints, 3))."""
+    with open(path) as f:
+        tok = f.read().split()
+    nc, npts, no = int(tok[0]), int(tok[1]), int(tok[2])
+    o = np.array(tok[3:3 + 4 * no], dtype=np.float64).reshape(no, 4)
+    rest = np.array(tok[3 + 4 * no:3 + 4 * no + 9 * nc + 3 * npts], dtype=np.float64)
+    if rest.size != 9 * nc + 3 * npts:
+        raise ValueError("truncated BAL file: %s" % path)
+    return dict(cam_index=o[:, 0].astype(np.int64), point_index=o[:, 1].astype(np.int64), xy=o[:, 2:4].copy(),
+                cameras=rest[:9 * nc].reshape(nc, 9), points=rest[9 * nc:].reshape(npts, 3))
+
+
+def bal_to_slampp(bal):
+    """BAL camera (9 parameters) -> the reference's 6 + 5. BAL projects p = -P / P.z with
+    P = R X + t, then f (1 + k1 |p|^2 + k2 |p|^4) p: the camera looks down -z. The reference
+    (BASolverBase.h:256-330) projects u = fx x / z + cx with x = R' X + t', then c + (1 + r^2 k) (u - c), r in
+    PIXELS and k = d / ((fx + fy) / 2). With F = diag(1, -1, -1): R' = F R, t' = F t, observations (x, -y),
+    fx = fy = f, cx = cy = 0; r = f |p| gives k = k1 / f^2, i.e. d = k1 / f. k2 has no counterpart and is dropped.
+    The reference's own converter is not in its tree (data/Readme.txt points to an external script), so this
+    mapping is derived from the two published camera models and checked by reprojection (tests/test_formats.py).
+    Returns (cams (nc, 6) [t' | axis-angle of R'], intr (nc, 5), points, obs (no, 4) point, camera, u, v)."""
+    from scipy.spatial.transform import Rotation
+    cam = bal["cameras"]
+    F = np.diag([1.0, -1.0, -1.0])
+    R = Rotation.from_rotvec(cam[:, :3]).as_matrix()
+    Rp = np.einsum("ij,cjk->cik", F, R)
+    cams = np.concatenate([cam[:, 3:6] @ F.T, Rotation.from_matrix(Rp).as_rotvec()], axis=1)
+    f = cam[:, 6]
+    intr = np.stack([f, f, np.zeros_like(f), np.zeros_like(f), cam[:, 7] / f], axis=1)
+    obs = np.stack([bal["point_index"].astype(np.float64), bal["cam_index"].astype(np.float64),
+                    bal["xy"][:, 0], -bal["xy"][:, 1]], axis=1)
+    return cams, intr, bal["points"].copy(), obs
+
+
+def convert_bal_file(path_bal, path_graph):
+    """BAL problem file -> VERTEX_CAM / VERTEX_XYZ / EDGE_PROJECT_P2MC graph the reference's parser reads."""
+    cams, intr, points, obs = bal_to_slampp(load_bal(path_bal))
+    save_ba_graph(path_graph, cams, intr, points, obs)
+
+
 def se2_linearize(poses, edges, info):
     """Hot-path inputs (synth.Problem) of a 2D pose graph at the given estimate: analytic Jacobians of
     the relative-pose error (the quantity reference include/slam/2DSolverBase.h:269-373 computes),
@@ -192,7 +280,7 @@ def se2_linearize(poses, edges, info):
     return Problem(name="se2_graph", dim=np.full(poses.shape[0], 3, dtype=np.int32), v0=v0, v1=v1, d0=3, d1=3, rd=3,
                    J0=np.ascontiguousarray(J0.transpose(0, 2, 1)).reshape(ne, 9),
                    J1=np.ascontiguousarray(J1.transpose(0, 2, 1)).reshape(ne, 9),
-                   Om=np.asarray(info, dtype=np.float64).reshape(ne, 9), r=r, unary_vertex=int(v0[0]), damping=0.0)
+                   Om=np.asarray(info, dtype=np.float64).reshape(ne, 9), r=r, unary_vertex=0, damping=0.0)
 
 
 def _hat(v):
@@ -236,7 +324,7 @@ def se3_linearize(poses, edges, info):
     return Problem(name="se3_graph", dim=np.full(poses.shape[0], 6, dtype=np.int32), v0=v0, v1=v1, d0=6, d1=6, rd=6,
                    J0=np.ascontiguousarray(J0.transpose(0, 2, 1)).reshape(ne, 36),
                    J1=np.ascontiguousarray(J1.transpose(0, 2, 1)).reshape(ne, 36),
-                   Om=np.asarray(info, dtype=np.float64).reshape(ne, 36), r=r, unary_vertex=int(v0[0]), damping=0.0)
+                   Om=np.asarray(info, dtype=np.float64).reshape(ne, 36), r=r, unary_vertex=0, damping=0.0)
 
 
 def se3_plus(poses, dx):
@@ -284,4 +372,4 @@ def ba_linearize(cams, intr, points, obs, cam_id=None, pt_id=None):
     return Problem(name="ba", dim=dim, v0=cam_id[co], v1=pt_id[po], d0=6, d1=3, rd=2,
                    J0=np.ascontiguousarray(J0.transpose(0, 2, 1)).reshape(no, 12),
                    J1=np.ascontiguousarray(PR.transpose(0, 2, 1)).reshape(no, 6),
-                   Om=np.tile(np.eye(2).ravel(), (no, 1)), r=obs[:, 2:4] - uv, unary_vertex=int(cam_id[co[0]]), damping=0.0)
+                   Om=np.tile(np.eye(2).ravel(), (no, 1)), r=obs[:, 2:4] - uv, unary_vertex=0, damping=0.0)

@@ -12,7 +12,10 @@ import numpy as np
 
 
 class Problem(dict):
-    """dict with attribute access: dim, v0, v1, d0, d1, rd, J0, J1, Om, r, unary_vertex, damping, name"""
+    """dict with attribute access: dim, v0, v1, d0, d1, rd, J0, J1, Om, r, unary_vertex, damping, name.
+    unary_vertex: the vertex whose diagonal block receives the unit unary factor -- vertex 0 in the reference's
+    default build (__AUTO_UNARY_FACTOR_ON_VERTEX_ZERO, include/slam/FlatSystem.h:331-337; pinned by
+    tests/golden/ba_lambda.npz, where vertex 0 is a landmark), whatever its type."""
     __getattr__ = dict.__getitem__
 
 
@@ -105,7 +108,7 @@ def ba_problem(nc, npts, nobs, seed, heavy_tail=True, interleave=False, spread=0
     return Problem(name=name, dim=dim, v0=cam_id[cam_of], v1=pt_id[pt_of], d0=6, d1=3, rd=2,
                    J0=np.ascontiguousarray(Jc.transpose(0, 2, 1)).reshape(nobs, 12),  # col-major 2x6
                    J1=np.ascontiguousarray(Jp.transpose(0, 2, 1)).reshape(nobs, 6),   # col-major 2x3
-                   Om=Om, r=r, unary_vertex=int(cam_id[cam_of[0]]), damping=1e-3 * float(max(h0, h1)),
+                   Om=Om, r=r, unary_vertex=0, damping=1e-3 * float(max(h0, h1)),
                    nc=nc, npts=npts, geometry=dict(R=R, C=C, X=X, f=f, cam_of=cam_of, pt_of=pt_of, cam_id=cam_id, pt_id=pt_id))
 
 
@@ -285,7 +288,7 @@ def landmark2d_problem(n_poses=80, n_lm=200, seed=32, interleave=False, name="lm
     return Problem(name=name, dim=dim, v0=pose_id[po], v1=lm_id[lo], d0=3, d1=2, rd=2,
                    J0=np.ascontiguousarray(J0.transpose(0, 2, 1)).reshape(ne, 6),
                    J1=np.ascontiguousarray(J1.transpose(0, 2, 1)).reshape(ne, 4),
-                   Om=Om, r=r, unary_vertex=int(pose_id[po[0]]), damping=1e-2)
+                   Om=Om, r=r, unary_vertex=0, damping=1e-2)
 
 
 def pose_graph_states(prob):
