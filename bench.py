@@ -15,17 +15,21 @@ separately, exactly as the reference amortizes it (metric 1).
 value = nnzb(Lambda upper incl. diagonal) x steps / wall time  [block-nnz/s], whole job.
 N > 1: landmarks are sharded over the ranks, every rank forms its partial Schur
 complement, packs the upper trapezoid of S | rhs, ONE RCCL all-reduce (torch.distributed "nccl")
-sums it, every rank factors S and back-substitutes its own landmarks.
-  --scaling weak (default): every rank brings its own Venice-sized landmark shard (530 304 points,
-    2 838 740 observations) seen by the same 871 cameras: the job is ONE bundle adjustment with
-    N x 530 304 landmarks, value = sum of the shards' block-nnz / time. Per-GPU work is fixed.
-  --scaling strong: the single Venice problem, landmarks dealt round-robin over the ranks. The dense
-    factor of the 5226^2 reduced system is replicated, so this mode is bounded by it.
+sums it, every rank factors S and back-substitutes its own landmarks. All of it is enqueued on ONE stream
+(the ctx adopts torch's current stream: no host synchronization around the collective).
+  --scaling strong (default = BASELINE config 4 / the metric): the ONE Venice problem, landmarks dealt
+    round-robin over the ranks; `value` is its block-nnz / time. The dense factor of the 5226^2 reduced
+    system and the collective are replicated work: the Amdahl bound is stated in config.parallelism.
+  the same run then times the weak-scaling variant as an EXTRA field (`weak_scaling`): every rank brings
+    its own Venice-sized landmark shard (530 304 points, 2 838 740 observations) seen by the same 871
+    cameras -- one bundle adjustment with N x 530 304 landmarks, per-GPU work fixed. --scaling weak makes
+    that variant the headline instead (labelled so).
 
 Extra fields: gn_iters_per_s (assembly + solve = one Gauss-Newton/LM iteration of device work),
 phase_ms, analyze_s, roofline (dominant kernel = MFMA f64 trailing update of the dense factor),
-cpu_baseline (the REFERENCE's own CLinearSolver_Schur compiled from /root/reference into
-oracle/_ref, timed on this box's host cores on the same Lambda).
+cpu_baseline (the REFERENCE's own solvers compiled from /root/reference into oracle/_ref, timed on this box's
+host cores: headline = its fastest path on the same Lambda (CLinearSolver_Schur + dense LLT for BA), `cholmod` =
+north_star's CLinearSolver_CholMod on a bounded sample), dropin_ms (the host-pointer entry of the boundary).
 """
 import argparse
 import json
@@ -55,9 +59,15 @@ def main():
                     help="reference backend of the cpu_baseline leg. auto = the reference's FASTEST path for the workload "
                          "(CLinearSolver_Schur + dense LLT for BA, UberBlock for pose graphs). north_star's CHOLMOD path "
                          "takes ~150 s per Venice-shaped solve (DESIGN.md 5): run it explicitly with --cpu-backend cholmod --cpu-solves 1")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="N > 1: weak = every rank brings its own Venice-sized landmark set seen by the same 871 "
-                         "cameras (per-GPU work fixed); strong = the one Venice problem sharded by landmarks")
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
+                    help="N > 1: strong (default, BASELINE config 4) = the one Venice problem sharded by landmarks; "
+                         "weak = every rank brings its own Venice-sized landmark set seen by the same 871 cameras")
+    ap.add_argument("--graph", default=None, help="take the workload from a graph file (EDGE_SE2 / EDGE3[:AXISANGLE] / "
+                    "VERTEX_CAM + VERTEX_XYZ + EDGE_PROJECT_P2MC) instead of the synthetic generator")
+    ap.add_argument("--cpu-cholmod", default="sample", choices=["sample", "full", "off"],
+                    help="north_star's CPU path (CLinearSolver_CholMod) timed in this run: on the whole Lambda when that takes "
+                         "seconds (pose graphs, Ladybug), on a quarter of the landmarks for the Venice shape (~12 s; the whole "
+                         "Lambda takes ~150 s: --cpu-cholmod full)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank path on a single GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0")
@@ -94,75 +104,108 @@ def main():
     # ---- problem (same seed on every rank) and device-resident inputs
     t0 = time.time()
     weak = world > 1 and args.scaling == "weak"
-    if weak and args.workload == "venice871":
+    graph_note = None
+    if args.graph:
+        from slam_plus_plus_amd import formats
+        prob, graph_note = formats.problem_from_graph(args.graph)
+        if "nc" in prob:  # BA input: the reference switches to Levenberg-Marquardt (src/slam_app/Main.cpp:203-208)
+            h = max(float(np.square(prob.J0).reshape(prob.v0.size, 6, 2).sum(axis=2).max()),
+                    float(np.square(prob.J1).reshape(prob.v0.size, 3, 2).sum(axis=2).max()))
+            prob["damping"] = 1e-3 * h
+        args.workload = os.path.basename(args.graph)
+    elif weak and args.workload == "venice871":
         # same cameras (deterministic circle), a different landmark / observation set per rank
         prob = synth.ba_problem(871, 530304, 2838740, 871 + rank, heavy_tail=True, name="venice871")
     else:
         prob = synth.make(args.workload)
     gen_s = time.time() - t0
-    ctx = api.Context(local_rank, api.FLAG_PROFILE)
-    st = ctx.assemble_analyze(prob.dim, prob.v0, prob.v1, prob.d0, prob.d1, prob.rd, prob.unary_vertex)
-    d_in = [api.DeviceArray.from_host(ctx, a.ravel()) for a in (prob.J0, prob.J1, prob.Om, prob.r)]
-    d_vals = api.DeviceArray(ctx, st.nvals)
-    d_eta = api.DeviceArray(ctx, st.n)
-    d_rhs = api.DeviceArray(ctx, st.n)
 
-    def assemble():
-        ctx.assemble_device(d_in[0].ptr, d_in[1].ptr, d_in[2].ptr, d_in[3].ptr, prob.damping, d_vals.ptr, d_eta.ptr)
+    # N > 1 over RCCL: everything runs on ONE non-blocking torch stream (the legacy default stream would serialize the
+    # ctx's internal streams against it); BENCH_FORCE_TORCH_STREAM=1 rehearses that stream set-up on a single GPU
+    use_torch_stream = (world > 1 and args.backend == "nccl") or bool(os.environ.get("BENCH_FORCE_TORCH_STREAM"))
+    if use_torch_stream:
+        torch.cuda.set_stream(torch.cuda.Stream())
 
-    assemble()
-    ctx.synchronize()
-    t0 = time.time()
-    if weak:
-        ctx.set_shard(0, 1)       # this rank owns ALL landmarks of its own problem (and its share of A / eta)
-    else:
-        ctx.set_shard(rank, world)
-    ctx.analyze(st, api.MODE_AUTO)
-    analyze_s = time.time() - t0
-    mode = ctx.info("MODE")
-    nnzb = st.nnzb
-
-    S = P = None
-    schur = mode in (api.MODE_SCHUR, api.MODE_SCHUR_SPARSE)
-    if schur and world > 1:
-        S = torch.empty(ctx.schur_buffer_size(), dtype=torch.float64, device="cuda")
-        P = torch.empty(ctx.schur_packed_size(), dtype=torch.float64, device="cuda")  # upper trapezoid only
-
-    def solve():
-        d_rhs.copy_from(d_eta)
-        if S is None:
-            code = ctx.factor_solve_device(d_vals.ptr, d_rhs.ptr)
-        else:
-            ctx.schur_form(d_vals.ptr, d_rhs.ptr, S.data_ptr())
-            ctx.schur_pack(S.data_ptr(), P.data_ptr())
+    class Job:
+        """one Lambda resident in HBM + everything a numeric solve needs; shard = (rank, world) of the landmark sharding"""
+        def __init__(self, prob, shard, flags):
+            self.prob = prob
+            self.ctx = ctx = api.Context(local_rank, flags)
+            if use_torch_stream:
+                # the ctx works on torch's current stream: the RCCL all-reduce is ordered behind the pack kernel and in
+                # front of the unpack kernel by the stream (torch orders its collective stream against the current one)
+                ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+            self.st = st = ctx.assemble_analyze(prob.dim, prob.v0, prob.v1, prob.d0, prob.d1, prob.rd, prob.unary_vertex)
+            self.d_in = [api.DeviceArray.from_host(ctx, a.ravel()) for a in (prob.J0, prob.J1, prob.Om, prob.r)]
+            self.d_vals = api.DeviceArray(ctx, st.nvals)
+            self.d_eta = api.DeviceArray(ctx, st.n)
+            self.d_rhs = api.DeviceArray(ctx, st.n)
+            self.assemble()
             ctx.synchronize()
-            dist.all_reduce(P)            # the one data-path collective: reduced camera system + reduced rhs
-            torch.cuda.synchronize()
-            ctx.schur_unpack(P.data_ptr(), S.data_ptr())
-            code = ctx.schur_finish(d_vals.ptr, S.data_ptr(), d_rhs.ptr)
-        if code != 0:
-            raise SystemExit("factorization failed (not positive definite): code %d" % code)
+            t0 = time.time()
+            ctx.set_shard(*shard)
+            ctx.analyze(st, api.MODE_AUTO)
+            self.analyze_s = time.time() - t0
+            self.mode = ctx.info("MODE")
+            self.schur = self.mode in (api.MODE_SCHUR, api.MODE_SCHUR_SPARSE)
+            self.S = self.P = None
+            if self.schur and world > 1:
+                self.S = torch.empty(ctx.schur_buffer_size(), dtype=torch.float64, device="cuda")
+                self.P = torch.empty(ctx.schur_packed_size(), dtype=torch.float64, device="cuda")  # upper trapezoid only
+
+        def assemble(self):
+            d = self.d_in
+            self.ctx.assemble_device(d[0].ptr, d[1].ptr, d[2].ptr, d[3].ptr, self.prob.damping, self.d_vals.ptr, self.d_eta.ptr)
+
+        def solve(self):
+            ctx = self.ctx
+            self.d_rhs.copy_from(self.d_eta)
+            if self.S is None:
+                code = ctx.factor_solve_device(self.d_vals.ptr, self.d_rhs.ptr)
+            else:
+                ctx.schur_form(self.d_vals.ptr, self.d_rhs.ptr, self.S.data_ptr())
+                ctx.schur_pack(self.S.data_ptr(), self.P.data_ptr())
+                if not use_torch_stream:
+                    ctx.synchronize()
+                dist.all_reduce(self.P)       # the one data-path collective: reduced camera system + reduced rhs
+                if not use_torch_stream:
+                    torch.cuda.synchronize()
+                ctx.schur_unpack(self.P.data_ptr(), self.S.data_ptr())
+                code = ctx.schur_finish(self.d_vals.ptr, self.S.data_ptr(), self.d_rhs.ptr)
+            if code != 0:
+                raise SystemExit("factorization failed (not positive definite): code %d" % code)
+
+        def timed(self, steps, warmup, debug_label=None):
+            """W untimed + exactly K timed Lambda-solves, barrier + synchronize on both sides, MAX over ranks [s]"""
+            self.ctx.set_profiling(False)
+            for _ in range(warmup):
+                self.solve()
+            self.ctx.synchronize()
+            barrier_sync()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                t1 = time.perf_counter()
+                self.solve()
+                if debug_label and os.environ.get("BENCH_DEBUG"):
+                    print("%s %.3f ms" % (debug_label, 1e3 * (time.perf_counter() - t1)), file=sys.stderr)
+            self.ctx.synchronize()
+            barrier_sync()
+            dt = time.perf_counter() - t0
+            if world > 1:
+                tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dt = float(tt.item())
+            return dt
+
+    job = Job(prob, (0, 1) if weak else (rank, world), api.FLAG_PROFILE)
+    ctx, st, mode, schur, analyze_s = job.ctx, job.st, job.mode, job.schur, job.analyze_s
+    d_in, d_vals, d_eta, d_rhs = job.d_in, job.d_vals, job.d_eta, job.d_rhs
+    assemble, solve = job.assemble, job.solve
+    nnzb = st.nnzb
 
     # ---- timed region: exactly K Lambda-solves, profiling instrumentation OFF (the hipEvents around
     # the phases and around every trailing-update launch cost a barrier packet each)
-    ctx.set_profiling(False)
-    for _ in range(args.warmup):
-        solve()
-    ctx.synchronize()
-    barrier_sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        t1 = time.perf_counter()
-        solve()
-        if os.environ.get("BENCH_DEBUG"):
-            print("step %.3f ms" % (1e3 * (time.perf_counter() - t1)), file=sys.stderr)
-    ctx.synchronize()
-    barrier_sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = job.timed(args.steps, args.warmup, "step")
     # ---- separate profiled pass: phase breakdown and the hipEvent-timed dominant kernel (last solve)
     ctx.set_profiling(True)
     for _ in range(3):
@@ -277,6 +320,19 @@ def main():
                     "what": "device linearization (CEdgeP2C3D, analytic) + assembly + Schur solve + ||dx|| + vertex update; "
                             "state reset by two device copies per iteration (included)"}
 
+    # ---- N > 1, strong headline: the weak-scaling variant as an extra field (its own problem per rank, own ctx)
+    weak_extra = None
+    if world > 1 and not weak and args.workload == "venice871" and not args.graph:
+        probw = synth.ba_problem(871, 530304, 2838740, 871 + rank, heavy_tail=True, name="venice871")
+        jobw = Job(probw, (0, 1), 0)
+        ksteps = max(3, args.steps // 2)
+        dtw = jobw.timed(ksteps, 2)
+        weak_extra = {"value": jobw.st.nnzb * world * ksteps / dtw, "unit": "block-nnz/s", "ms_per_step": 1e3 * dtw / ksteps,
+                      "steps": ksteps, "what": "every rank brings its own Venice-sized landmark shard (530304 points, 2838740 "
+                      "observations, seed 871 + rank) seen by the same 871 cameras: ONE bundle adjustment with %d x 530304 "
+                      "landmarks, per-GPU work fixed; value = sum of the shards' block-nnz / time" % world}
+        del jobw
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -284,51 +340,142 @@ def main():
 
     x = x_solve
     total_nnzb = nnzb * world if weak else nnzb
+    mode_name = {api.MODE_SCHUR: "schur+dense", api.MODE_SCHUR_SPARSE: "schur+sparse reduced system",
+                 api.MODE_SPARSE: "sparse multifrontal"}[mode]
+    parallelism = "single GPU"
+    if world > 1 and schur:
+        rep = phase["factor"] + phase["trisolve"]                      # replicated on every rank
+        shard = phase["schur_inv"] + phase["schur_gemm"] + phase["schur_rhs"] + phase["backsubst"]  # this rank's share
+        parallelism = ("%s: landmark shards x%d + one RCCL all-reduce of the packed reduced camera system (%.0f MB) on the ctx "
+                       "stream; per solve %.2f ms replicated (dense factor + triangular solves) + %.2f ms sharded on this rank "
+                       "(x%d = %.2f ms of single-GPU work): Amdahl bound %.2fx before the collective" % (
+                           "weak (871 cameras, 530304 landmarks per GPU)" if weak else "strong (the one Venice problem)", world,
+                           8e-6 * ctx.schur_packed_size(), rep, shard, world, shard * world,
+                           (rep + shard * world) / max(rep, 1e-9)))
+    elif world > 1:
+        parallelism = "replicas only: a pose graph of this size does not shard (DESIGN.md 6); every rank solves the same problem"
     out = {
         "metric": METRIC, "value": total_nnzb * args.steps / dt, "unit": "block-nnz/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-        "higher_is_better": True, "scaling": "weak" if (weak or world == 1) else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "%s-shaped synthetic BA (%d cams, %d points, %d observations, LM-damped)" % (
-            args.workload, prob.get("nc", 0), prob.get("npts", 0), prob.v0.size) if "nc" in prob else args.workload,
-            "nnzb": int(nnzb), "n": int(st.n), "mode": {api.MODE_SCHUR: "schur+dense", api.MODE_SCHUR_SPARSE: "schur+sparse reduced system",
-                                                            api.MODE_SPARSE: "sparse multifrontal"}[mode],
+        "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f64",
+        "data": "graph file" if args.graph else "synthetic",
+        "config": {"workload": graph_note if graph_note else ("%s-shaped synthetic BA (%d cams, %d points, %d observations, LM-damped)" % (
+            args.workload, prob.get("nc", 0), prob.get("npts", 0), prob.v0.size) if "nc" in prob else args.workload),
+            "nnzb": int(nnzb), "n": int(st.n), "mode": mode_name,
             "n_reduced": int(ctx.info("N_REDUCED")), "schur_pairs": int(ctx.info("SCHUR_PAIRS")),
-            "parallelism": ("%s: landmark shards x%d + one RCCL all-reduce of the packed reduced camera system (%.0f MB)" % (
-                "weak (871 cameras, 530304 landmarks per GPU)" if weak else "strong (one Venice problem)", world,
-                8e-6 * ctx.schur_packed_size())) if (world > 1 and schur) else "single GPU"},
+            "parallelism": parallelism},
         "gn_iters_per_s": gn_steps / dt_gn, "ms_per_gn_iter": 1e3 * dt_gn / gn_steps, "assemble_ms": assemble_ms,
         "phase_ms": {k: round(v, 4) for k, v in phase.items()},
         "phase_ms_note": "separate pass with SPP_FLAG_PROFILE on (hipEvents per phase and per trailing-update launch); ms_per_step is timed with profiling off", "analyze_s": round(analyze_s, 3),
         "generate_s": round(gen_s, 2), "solution_norm": float(np.linalg.norm(x)),
     }
+    if world == 1:
+        out["scaling_note"] = "one GPU: the whole problem (strong and weak coincide)"
+    if weak_extra is not None:
+        out["weak_scaling"] = weak_extra
     if resident is not None:
         out["gn_resident"] = resident
-    # ---- roofline of the dominant kernel (hipEvents on the ctx stream, last timed solve)
-    if dom_n > 0 and dom_ms > 0:
-        achieved = dom_flops / (dom_ms * 1e-3) * 1e-12
-        traffic = None
+
+    # ---- HBM counter traffic of the dominant kernel: a rocprofv3 --pmc run of an EARLIER round (separate passes, the
+    # guide's corrections), not of this run; the source file is named beside the number
+    def pmc_traffic(key):
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get(args.workload, {}).get("bytes_per_launch")
-            except Exception:
-                traffic = None
+        try:
+            rec = json.load(open(pmc)).get(key)
+            if not rec:
+                return None, "no PMC record for this workload in profiles/pmc_traffic.json"
+            return rec.get("bytes_per_launch"), "profiles/pmc_traffic.json[%s] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of %s, not this run)" % (
+                key, rec.get("source", "an earlier profiling run"))
+        except Exception:
+            return None, "no PMC record for this workload under profiles/"
+
+    nobs, npair, nlm, nposes = ctx.info("N_OBS"), ctx.info("SCHUR_PAIRS"), ctx.info("N_LANDMARKS"), ctx.info("N_POSES")
+    sch_ms = phase["schur_inv"] + phase["schur_gemm"] + phase["schur_rhs"] + phase["backsubst"]
+    schur_hbm = None
+    if schur and sch_ms > 0:
+        # SURVEY 8d, "Schur": read 144 no + 72 np + 288 nnzb(A) + 8 n; write 288 nnzb(S) + 8 n  (algorithmic: every
+        # input read once, every output written once; what the pair lists re-gather is NOT counted)
+        nnzb_A = int(nnzb - nobs - nlm)
+        sch_bytes = 144.0 * nobs + 72.0 * nlm + 288.0 * nnzb_A + 8.0 * st.n + 288.0 * ctx.info("S_NNZB") + 8.0 * st.n
+        schur_hbm = {"achieved": sch_bytes / (sch_ms * 1e-3) * 1e-9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                     "frac": sch_bytes / (sch_ms * 1e-3) * 1e-9 / PEAK_HBM_GBS, "algorithmic_bytes": sch_bytes, "ms": sch_ms,
+                     "bytes_touched_by_pair_lists": 288.0 * npair,
+                     "note": "SURVEY 8d bytes (inputs once, outputs once) over the four Schur phases; the S accumulation gathers "
+                             "288 B per block product through its pair lists (bytes_touched_by_pair_lists), which the synthetic "
+                             "co-visibility (observers drawn from a 209-camera window) does not let a cache absorb"}
+    # ---- roofline of the dominant kernel
+    if mode == api.MODE_SCHUR and dom_n > 0 and dom_ms > 0:
+        achieved = dom_flops / (dom_ms * 1e-3) * 1e-12
+        traffic, traffic_src = pmc_traffic(args.workload)
+        n_red = float(ctx.info("N_REDUCED"))
+        fac_flops = n_red ** 3 / 3.0
+        mfma_meas = ctx.microbench_mfma_f64(4000)
         out["roofline"] = {"bound": "mfma", "kernel": "spp::gemm_tn_mixed_kernel (MFMA f64 16x16x4 trailing update of the dense factor: 128x128 tiles, the tail of every launch cut into 64x64 quarters)",
                            "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
+                           "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                            "launches_per_solve": int(dom_n), "avg_launch_ms": dom_ms / dom_n,
                            "flops_per_launch": dom_flops / dom_n,
+                           "factor_phase": {"flops": fac_flops, "ms": phase["factor"], "achieved": fac_flops / (phase["factor"] * 1e-3) * 1e-12,
+                                            "frac": fac_flops / (phase["factor"] * 1e-3) * 1e-12 / PEAK_FP64_MFMA_TFLOPS,
+                                            "frac_of_measured_mfma_loop": fac_flops / (phase["factor"] * 1e-3) * 1e-12 / mfma_meas,
+                                            "what": "n_reduced^3 / 3 flops over the WHOLE dense factorization (serial diagonal-block chain included)"},
+                           "whole_step": {"flops": fac_flops + 216.0 * npair, "ms": 1e3 * dt / args.steps,
+                                          "frac": (fac_flops + 216.0 * npair) / (dt / args.steps) * 1e-12 / PEAK_FP64_MFMA_TFLOPS},
                            "standalone_update_tflops": (lambda m: (128.0 * m * (m + 1) + 256.0 * m) / ctx.microbench_update(m, 5) * 1e-9)(5120),
-                           "measured_mfma_f64_peak": ctx.microbench_mfma_f64(4000),
+                           "measured_mfma_f64_peak": mfma_meas,
                            "measured_copy_gbs": ctx.microbench_copy(1 << 30, 10),
                            "measured_ctile_rw_gbs": ctx.microbench_ctile(8192, 5)}
-        # the HBM-bound part of the solve, for reference: algorithmic bytes / time of the Schur phases
-        sch_ms = phase["schur_inv"] + phase["schur_gemm"] + phase["schur_rhs"] + phase["backsubst"]
-        if sch_ms > 0:
-            nobs, npair = ctx.info("N_OBS"), ctx.info("SCHUR_PAIRS")
-            sch_bytes = 144 * nobs * 4 + 288 * npair + 72 * ctx.info("N_LANDMARKS") + 288 * ctx.info("N_POSES") ** 2 / 2
-            out["schur_hbm"] = {"achieved": sch_bytes / (sch_ms * 1e-3) * 1e-9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                "frac": sch_bytes / (sch_ms * 1e-3) * 1e-9 / PEAK_HBM_GBS}
+        if schur_hbm:
+            out["schur_hbm"] = schur_hbm
+    elif mode == api.MODE_SCHUR and schur_hbm:
+        # a reduced camera system too small for the MFMA trailing-update kernel (Ladybug-49: 294 x 294, factored inside one
+        # workgroup): the landmark elimination is what is left to price, against HBM
+        traffic, traffic_src = pmc_traffic(args.workload)
+        out["roofline"] = dict(schur_hbm, bound="hbm", kernel="the four Schur phases (spp::cinv_kernel, obs_kernel, s_accum_kernel, rhs / "
+                               "back-substitution kernels); the %d x %d reduced system is factored by single-workgroup kernels" % (
+                                   ctx.info("N_REDUCED"), ctx.info("N_REDUCED")), traffic=traffic, traffic_source=traffic_src,
+                               dense_factor={"flops": float(ctx.info("N_REDUCED")) ** 3 / 3.0, "ms": phase["factor"] + phase["trisolve"]})
+    elif mode == api.MODE_SCHUR_SPARSE and schur_hbm:
+        # BASELINE config 5 shape: the reduced camera system is sparse and small next to the landmark elimination
+        traffic, traffic_src = pmc_traffic(args.workload)
+        out["roofline"] = dict(schur_hbm, bound="hbm", kernel="the four Schur phases (spp::cinv_kernel, obs_kernel, s_accum_kernel, rhs / "
+                               "back-substitution kernels): HBM-bound landmark elimination", traffic=traffic, traffic_source=traffic_src,
+                               sparse_factor={"flops": int(ctx.info("FACTOR_FLOPS")), "ms": phase["factor"] + phase["trisolve"]})
+    elif mode == api.MODE_SPARSE:
+        # pose graphs: supernodal multifrontal factor + solves; bytes = 8 (nnz Lambda + nnz R) + 16 nnz R
+        fs_ms = phase["factor"] + phase["trisolve"]
+        sbytes, fflops = float(ctx.info("SOLVE_BYTES")), float(ctx.info("FACTOR_FLOPS"))
+        if fs_ms > 0:
+            traffic, traffic_src = pmc_traffic(args.workload)
+            out["roofline"] = {"bound": "hbm", "kernel": "spp::front_lds_kernel / front_fwd_kernel / front_bwd_kernel (supernodal multifrontal "
+                               "factor + triangular solves, one launch per tree level and front size class)",
+                               "achieved": sbytes / (fs_ms * 1e-3) * 1e-9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                               "frac": sbytes / (fs_ms * 1e-3) * 1e-9 / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                               "algorithmic_bytes": sbytes, "factor_flops": fflops, "ms": fs_ms,
+                               "mfma_frac": fflops / (max(phase["factor"], 1e-9) * 1e-3) * 1e-12 / PEAK_FP64_MFMA_TFLOPS,
+                               "tree_levels": int(ctx.info("N_LEVELS")), "supernodes": int(ctx.info("N_SUPERNODES")),
+                               "note": "LATENCY-bound, not bandwidth-bound: a few MB of factor spread over %d tree levels; neither "
+                                       "roofline is approached at this size (SURVEY 7.3, 8d)" % int(ctx.info("N_LEVELS"))}
+    # ---- the drop-in boundary's host-pointer entry (spp_factor_solve): Lambda in the ctx's page-locked staging buffer
+    # (where the adapter flattens it) -> H2D -> solve -> D2H of the solution; never `value`
+    if world == 1:
+        try:
+            lam_host = d_vals.download()
+            eta_host = d_eta.download()
+            t0 = time.perf_counter()
+            stage = ctx.host_staging(st.nvals)
+            stage[:] = lam_host                       # stands for the adapter's per-block memcpy flatten
+            flat_ms = 1e3 * (time.perf_counter() - t0)
+            ctx.factor_solve(stage, eta_host)          # warm
+            t0 = time.perf_counter()
+            for _ in range(3):
+                code, xd = ctx.factor_solve(stage, eta_host)
+            drop_ms = 1e3 * (time.perf_counter() - t0) / 3
+            out["dropin_ms"] = {"h2d_solve_d2h": drop_ms, "flatten_memcpy": flat_ms, "lambda_mb": 8e-6 * st.nvals,
+                                "rel_diff_vs_resident": float(np.linalg.norm(xd - x) / np.linalg.norm(x)),
+                                "what": "spp_factor_solve from the ctx's page-locked staging buffer (spp_host_staging): PCIe-inclusive, never `value`"}
+        except Exception as e:  # noqa: BLE001
+            out["dropin_ms"] = {"failed": repr(e)}
     # ---- CPU baseline: the reference itself (oracle/_ref), same Lambda, bounded sample
     if not args.no_cpu_baseline and world == 1 and ctx.info("N_REDUCED") <= 8192:  # the reference's Schur solve is dense: 60000^2 does not fit its path
         try:
@@ -350,6 +497,35 @@ def main():
                                                       "cholmod": "CLinearSolver_CholMod", "csparse": "CLinearSolver_CSparse"}[backend],
                                                      args.cpu_solves, min(secs)),
                                        "rel_diff_gpu_vs_reference": float(np.linalg.norm(x - xr) / np.linalg.norm(xr))}
+                out["cpu_baseline"]["headline_backend"] = (
+                    "the reference's FASTEST path for this workload (%s); north_star's CHOLMOD path is the `cholmod` entry" % backend)
+                # ---- north_star's CPU path: CLinearSolver_CholMod (src/slam/LinearSolver_CholMod.cpp:264-358: analyze + factorize
+                # + solve on the whole Lambda, no Schur complement, analysis redone every call), same box, same run
+                if args.cpu_cholmod != "off" and backend != "cholmod":
+                    full = args.cpu_cholmod == "full" or not schur or nnzb <= 200000
+                    if full:
+                        code, xc, sec = orc.RefSolver("cholmod", lam).solve(lam.vals, eta)
+                        out["cpu_baseline"]["cholmod"] = {
+                            "value": nnzb / sec, "unit": "block-nnz/s", "cores": 1, "seconds": sec,
+                            "sample": "one full Lambda-solve of the same %s system by the reference's CLinearSolver_CholMod" % args.workload,
+                            "rel_diff_gpu_vs_cholmod": float(np.linalg.norm(x - xc) / np.linalg.norm(xc))}
+                    else:
+                        # bounded sample: the same generator with a quarter of the landmarks (all 871 cameras), assembled by the HIP
+                        # kernels in a second ctx; the whole Venice-shaped Lambda takes ~150 s per CHOLMOD solve
+                        ps = synth.ba_problem(prob.nc, prob.npts // 4, prob.v0.size // 4, 871, heavy_tail=True, name="venice871_quarter")
+                        js = Job(ps, (0, 1), 0)
+                        lam_s, eta_s = js.st.with_vals(js.d_vals.download()), js.d_eta.download()
+                        js.solve()
+                        xs = js.d_rhs.download()
+                        del js
+                        code, xc, sec = orc.RefSolver("cholmod", lam_s).solve(lam_s.vals, eta_s)
+                        out["cpu_baseline"]["cholmod"] = {
+                            "value": lam_s.nnzb / sec, "unit": "block-nnz/s", "cores": 1, "seconds": sec,
+                            "sample": "one Lambda-solve by the reference's CLinearSolver_CholMod of a QUARTER-size sample of the workload "
+                                      "(same generator: 871 cameras, %d points, %d observations, %d upper blocks); the whole Venice-shaped "
+                                      "Lambda takes 150-154 s per CHOLMOD solve (2.2e4 block-nnz/s, measured 2026-10-04 in the development "
+                                      "container, 1 thread; --cpu-cholmod full repeats it here)" % (ps.npts, ps.v0.size, lam_s.nnzb),
+                            "rel_diff_gpu_vs_cholmod": float(np.linalg.norm(xs - xc) / np.linalg.norm(xc))}
             else:
                 out["cpu_baseline"] = {"value": None, "unit": "block-nnz/s", "cores": 1, "kind": "reference",
                                        "sample": "oracle/_ref/libspp_ref.so not present"}

@@ -55,18 +55,19 @@ protected:
 	size_t m_n_sym_blocks, m_n_sym_cols;
 	std::vector<int64_t> m_col_ptr, m_row_idx, m_blk_off;
 	std::vector<int32_t> m_dim;
-	std::vector<double> m_vals;
+	double *m_p_vals; /**< flattened block values: page-locked memory owned by the ctx (spp_host_staging) */
+	size_t m_n_vals;
 
 public:
 	inline CLinearSolver_HIP(int n_device = 0, int n_mode = SPP_MODE_AUTO)
 		:m_p_ctx(0), m_n_device(n_device), m_n_mode(n_mode), m_b_have_symbolic(false),
-		m_n_sym_blocks(0), m_n_sym_cols(0)
+		m_n_sym_blocks(0), m_n_sym_cols(0), m_p_vals(0), m_n_vals(0)
 	{}
 
 	/** copies configuration only, never state (LinearSolver_UberBlock.h:74-76) */
 	inline CLinearSolver_HIP(const CLinearSolver_HIP &r_other)
 		:m_p_ctx(0), m_n_device(r_other.m_n_device), m_n_mode(r_other.m_n_mode),
-		m_b_have_symbolic(false), m_n_sym_blocks(0), m_n_sym_cols(0)
+		m_b_have_symbolic(false), m_n_sym_blocks(0), m_n_sym_cols(0), m_p_vals(0), m_n_vals(0)
 	{}
 
 	inline ~CLinearSolver_HIP()
@@ -87,7 +88,6 @@ public:
 		if(m_p_ctx)
 			spp_free_memory(m_p_ctx);
 		m_b_have_symbolic = false;
-		std::vector<double>().swap(m_vals);
 	}
 
 	inline void Clear_SymbolicDecomposition()
@@ -118,7 +118,7 @@ public:
 			if(!SymbolicDecomposition_Blocky(r_lambda) || !Flatten_Values(r_lambda))
 				throw std::runtime_error("libspp_hip adapter: the block structure of lambda changed while it was flattened");
 		}
-		int n_result = Check(spp_factor_solve(m_p_ctx, &m_vals[0], r_eta.data()));
+		int n_result = Check(spp_factor_solve(m_p_ctx, m_p_vals, r_eta.data()));
 		return n_result == SPP_OK; // SPP_NOT_POSDEF leaves eta untouched, like the reference
 	}
 
@@ -183,7 +183,10 @@ protected:
 			}
 		}
 		m_col_ptr[n] = int64_t(m_row_idx.size());
-		m_vals.resize(size_t(n_off));
+		m_n_vals = size_t(n_off);
+		m_p_vals = spp_host_staging(m_p_ctx, n_off); // page-locked: spp_factor_solve() then copies at the link's DMA rate
+		if(!m_p_vals)
+			throw std::bad_alloc();
 		m_n_sym_cols = n;
 		m_n_sym_blocks = m_row_idx.size();
 	}
@@ -211,7 +214,7 @@ protected:
 				CUberBlockMatrix::_TyConstMatrixXdRef t_block = r_lambda.t_Block_AtColumn(i, j);
 				if(int32_t(t_block.rows()) != m_dim[n_row] || int32_t(t_block.cols()) != m_dim[i])
 					return false;
-				memcpy(&m_vals[size_t(m_blk_off[n_blk])], t_block.data(),
+				memcpy(m_p_vals + size_t(m_blk_off[n_blk]), t_block.data(),
 					size_t(t_block.rows()) * size_t(t_block.cols()) * sizeof(double)); // column-major dense block
 				++ n_blk;
 			}

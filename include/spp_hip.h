@@ -69,6 +69,11 @@ void spp_destroy(spp_ctx *ctx);
 /* drops factor/workspaces but keeps the ctx usable (Free_Memory, LinearSolver_UberBlock.h:88-121) */
 int spp_free_memory(spp_ctx *ctx);
 int spp_last_error(const spp_ctx *ctx, char *buf, size_t buf_size);
+/* Page-locked host buffer of at least n_doubles doubles, owned by the ctx (grows, freed by spp_destroy), or NULL
+ * when it cannot be had. The adapter flattens Lambda's blocks straight into it (the role of the m_vals vector) so
+ * that the host-pointer entry spp_factor_solve() copies to the device at the DMA rate of the link instead of through
+ * the runtime's pageable bounce buffers: the reference's own workspace reuse, LinearSolver_UberBlock.h:332-348. */
+double *spp_host_staging(spp_ctx *ctx, int64_t n_doubles);
 /* run all work of this ctx on an externally owned hipStream_t (e.g. torch's current stream) */
 int spp_set_stream(spp_ctx *ctx, void *hip_stream);
 int spp_synchronize(spp_ctx *ctx);

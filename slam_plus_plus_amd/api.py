@@ -26,7 +26,7 @@ PHASES = ["permute", "schur_inv", "schur_gemm", "schur_rhs", "factor", "trisolve
 
 # every symbol include/spp_hip.h declares (tests/test_abi.py checks the .so exports them all)
 EXPORTS = [
-    "spp_create", "spp_destroy", "spp_free_memory", "spp_last_error", "spp_set_stream", "spp_synchronize",
+    "spp_create", "spp_destroy", "spp_free_memory", "spp_last_error", "spp_host_staging", "spp_set_stream", "spp_synchronize",
     "spp_analyze", "spp_set_shard", "spp_get_info", "spp_get_ordering", "spp_factor_solve",
     "spp_factor_solve_device", "spp_schur_buffer_size", "spp_schur_form", "spp_schur_finish",
     "spp_schur_packed_size", "spp_schur_pack", "spp_schur_unpack",
@@ -61,6 +61,7 @@ def load_library():
         "spp_destroy": (None, [vp]),
         "spp_free_memory": (cint, [vp]),
         "spp_last_error": (cint, [vp, ctypes.c_char_p, ctypes.c_size_t]),
+        "spp_host_staging": (vp, [vp, i64]),
         "spp_set_stream": (cint, [vp, vp]),
         "spp_synchronize": (cint, [vp]),
         "spp_analyze": (cint, [vp, i64, vp, vp, vp, vp, cint]),
@@ -272,6 +273,14 @@ class Context:
     def synchronize(self):
         return self._check(self.lib.spp_synchronize(self.h))
 
+    def host_staging(self, n):
+        """numpy view of the ctx's page-locked host buffer (spp_host_staging): fill it with the block values and pass
+        it to factor_solve() -- the host-pointer entry then copies at the DMA rate of the link"""
+        p = self.lib.spp_host_staging(self.h, int(n))
+        if not p:
+            raise MemoryError(self.last_error())
+        return np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_double)), shape=(int(n),))
+
     # --- numeric
     def factor_solve(self, vals, rhs):
         vals = np.ascontiguousarray(vals, dtype=np.float64)
@@ -382,12 +391,33 @@ class CLinearSolver_HIP:
     def SymbolicDecomposition_Blocky(self, r_lambda):
         self._ctx.analyze(r_lambda, self._mode)
         self._have_symbolic = True
-        self._sig = (r_lambda.nb, r_lambda.nnzb)
+        self._sig = self._signature(r_lambda)
         return True
+
+    @staticmethod
+    def _signature(r_lambda):
+        """Fingerprint of the block STRUCTURE (not only of its two counts: one edge replaced by another keeps both):
+        a 64-bit hash of the column pointers, block rows and block sizes; the arrays' identities short-cut the
+        common case of the same structure object coming back every iteration."""
+        ident = (id(r_lambda.col_ptr), id(r_lambda.row_idx), id(r_lambda.dim))
+        try:
+            import xxhash
+            h = xxhash.xxh3_64()
+            for a in (r_lambda.col_ptr, r_lambda.row_idx, r_lambda.dim):
+                h.update(np.ascontiguousarray(a).view(np.uint8))
+            digest = h.intdigest()
+        except ImportError:
+            import zlib
+            digest = 0
+            for a in (r_lambda.col_ptr, r_lambda.row_idx, r_lambda.dim):
+                digest = zlib.adler32(np.ascontiguousarray(a).view(np.uint8), digest)
+        return (r_lambda.nb, r_lambda.nnzb, digest, ident)
 
     def Solve_PosDef_Blocky(self, r_lambda, r_eta):
         assert r_eta.shape[0] == r_lambda.n, "eta length must equal the matrix dimension"
-        if not self._have_symbolic or self._sig != (r_lambda.nb, r_lambda.nnzb):
+        if not self._have_symbolic or self._sig is None or (
+                self._sig[3] != (id(r_lambda.col_ptr), id(r_lambda.row_idx), id(r_lambda.dim))
+                and self._sig[:3] != self._signature(r_lambda)[:3]) or self._sig[:2] != (r_lambda.nb, r_lambda.nnzb):
             self.SymbolicDecomposition_Blocky(r_lambda)
         code, x = self._ctx.factor_solve(r_lambda.vals, r_eta)
         if code == SPP_NOT_POSDEF:

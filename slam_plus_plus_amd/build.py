@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libspp_hip.so")
 SOURCES = ["spp_api.cpp", "spp_symbolic.cpp", "spp_dense.hip", "spp_schur.hip", "spp_sparse.hip",
-           "spp_assemble.hip", "spp_geometry.hip", "spp_stubs.cpp"]
+           "spp_assemble.hip", "spp_geometry.hip"]
 
 
 def _hipcc():

@@ -159,6 +159,8 @@ void spp_destroy(spp_ctx *ctx)
 	}
 	if(ctx->dense.h_chain_err)
 		(void)hipHostFree(ctx->dense.h_chain_err);
+	if(ctx->h_staging)
+		(void)hipHostFree(ctx->h_staging);
 	if(ctx->timer.created)
 		for(int i = 0; i < 2 * SPP_N_PHASES; ++ i)
 			(void)hipEventDestroy(ctx->timer.ev[i]);
@@ -176,6 +178,30 @@ int spp_last_error(const spp_ctx *ctx, char *buf, size_t buf_size)
 	strncpy(buf, ctx->last_error.c_str(), buf_size - 1);
 	buf[buf_size - 1] = 0;
 	return SPP_OK;
+}
+
+double *spp_host_staging(spp_ctx *ctx, int64_t n_doubles)
+{
+	if(!ctx || n_doubles < 0)
+		return nullptr;
+	if((size_t)n_doubles <= ctx->h_staging_cap && ctx->h_staging)
+		return ctx->h_staging;
+	(void)hipSetDevice(ctx->device);
+	(void)hipStreamSynchronize(ctx->stream); // a copy out of the old buffer may still be in flight
+	if(ctx->h_staging) {
+		(void)hipHostFree(ctx->h_staging);
+		ctx->h_staging = nullptr;
+		ctx->h_staging_cap = 0;
+	}
+	const size_t want = (size_t)(n_doubles > 0 ? n_doubles : 1);
+	if(hipHostMalloc((void**)&ctx->h_staging, want * sizeof(double), hipHostMallocDefault) != hipSuccess) {
+		(void)hipGetLastError();
+		ctx->h_staging = nullptr;
+		ctx->last_error = "hipHostMalloc of the staging buffer failed";
+		return nullptr;
+	}
+	ctx->h_staging_cap = want;
+	return ctx->h_staging;
 }
 
 int spp_set_stream(spp_ctx *ctx, void *hip_stream)
@@ -225,8 +251,13 @@ int spp_analyze(spp_ctx *ctx, int64_t nb, const int64_t *col_ptr, const int64_t 
 		return SPP_E_BADARG;
 	SPP_TRY(ctx)
 	SPP_REQUIRE(nb > 0 && col_ptr && row_idx && blk_off && dim, SPP_E_BADARG, "spp_analyze: null or empty structure");
+	SPP_REQUIRE(col_ptr[0] == 0 && col_ptr[nb] >= nb, SPP_E_BADARG, "spp_analyze: column pointers must start at 0 and hold every diagonal block");
 	SPP_HIP_CHECK(hipSetDevice(ctx->device));
-	Structure &st = ctx->st;
+	// The structure is validated into a local object and only then committed: a rejected call must not leave the
+	// sizes of the NEW structure beside the plan of the OLD one (the next solve would copy the wrong extents).
+	// The old plan is dropped first in any case -- after a failed analyze the ctx is "not analyzed".
+	ctx->mode = -1;
+	Structure st;
 	st.nb = nb;
 	st.nnzb = col_ptr[nb];
 	st.col_ptr.assign(col_ptr, col_ptr + nb + 1);
@@ -252,13 +283,15 @@ int spp_analyze(spp_ctx *ctx, int64_t nb, const int64_t *col_ptr, const int64_t 
 		}
 		SPP_REQUIRE(row_idx[col_ptr[j + 1] - 1] == j, SPP_E_BADARG, "diagonal block missing (must be last in its column)");
 	}
+	ctx->st = std::move(st);
+	Structure &st_ref = ctx->st;
 	ctx->schur.release_all();
 	sparse_release(ctx);
 	int dp, dl;
 	int chosen = mode;
 	if(mode == SPP_MODE_AUTO) {
 		chosen = SPP_MODE_SPARSE;
-		if(schur_applicable(st, &dp, &dl)) {
+		if(schur_applicable(st_ref, &dp, &dl)) {
 			// dense reduced system while it is small enough for the MFMA dense factor to win (Venice: 5226),
 			// sparse (supernodal) reduced system beyond: a 10k-camera S is 28.8 GB dense and mostly zeros
 			int64_t n_red = 0;
@@ -290,7 +323,7 @@ int spp_analyze(spp_ctx *ctx, int64_t nb, const int64_t *col_ptr, const int64_t 
 			ctx->order.push_back(ctx->schur.pose_block[i]);
 		// landmarks are eliminated FIRST in elimination terms; the reference lists them last in its
 		// guided ordering (poses | landmarks), which is what order[] reports
-		for(int64_t j = 0; j < st.nb; ++ j)
+		for(int64_t j = 0; j < st_ref.nb; ++ j)
 			if(ctx->schur.is_lm[j])
 				ctx->order.push_back(j);
 	} else
@@ -442,9 +475,10 @@ int spp_schur_finish(spp_ctx *ctx, const double *d_vals, double *d_S_rhs, double
 	SPP_TRY(ctx)
 	SPP_REQUIRE(ctx->mode == SPP_MODE_SCHUR, SPP_E_STATE, "spp_schur_finish: analyze in Schur mode first");
 	SPP_HIP_CHECK(hipSetDevice(ctx->device));
-	int ret = schur_finish(ctx, d_vals, d_S_rhs, d_rhs_inout);
+	int ret = schur_finish(ctx, d_vals, d_S_rhs, d_rhs_inout); // synchronizes (status fetch)
 	phase_end(ctx, SPP_PHASE_TOTAL);
 	phases_collect(ctx);
+	dense_chain_check(ctx); // a timed-out backward substitution is reported by the call that produced the result
 	return ret;
 	SPP_CATCH(ctx)
 }
@@ -821,6 +855,7 @@ int spp_dense_posv(spp_ctx *ctx, double *d_A, int64_t n, int64_t ld, double *d_b
 			hipMemcpyDeviceToDevice, ctx->stream));
 	}
 	SPP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	dense_chain_check(ctx);
 	return ret;
 	SPP_CATCH(ctx)
 }

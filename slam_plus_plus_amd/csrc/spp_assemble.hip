@@ -67,14 +67,16 @@ void assemble_analyze(spp_ctx *ctx, int64_t nv, const int32_t *dim, int64_t ne, 
 		(d0 == 6 && d1 == 6 && rd == 6) || (d0 == 3 && d1 == 2 && rd == 2), SPP_E_UNSUPPORTED,
 		"edge group (d0, d1, rd) not instantiated: (6,3,2) (3,3,3) (6,6,6) (3,2,2)");
 	SPP_REQUIRE(ne < (int64_t(1) << 30), SPP_E_UNSUPPORTED, "too many edges for 31-bit edge indices");
-	assemble_release(ctx);
-	AssemblePlan *ap = new AssemblePlan;
-	ctx->assemble = ap;
-	ap->d0 = d0; ap->d1 = d1; ap->rd = rd; ap->nv = nv; ap->ne = ne; ap->unary_vertex = unary_vertex;
+	assemble_release(ctx); // after a rejected call the ctx has NO assembly plan (spp_assemble_device then fails its state check)
 	for(int64_t e = 0; e < ne; ++ e) {
 		SPP_REQUIRE(v0[e] >= 0 && v0[e] < nv && v1[e] >= 0 && v1[e] < nv && v0[e] != v1[e], SPP_E_BADARG, "bad edge");
 		SPP_REQUIRE(dim[v0[e]] == d0 && dim[v1[e]] == d1, SPP_E_BADARG, "vertex width does not match the edge group");
 	}
+	SPP_REQUIRE(unary_vertex < nv, SPP_E_BADARG, "unary_vertex out of range");
+	// built in a local object, installed in the ctx only when complete
+	struct PlanGuard { AssemblePlan *p; ~PlanGuard() { delete p; } } guard = {new AssemblePlan};
+	AssemblePlan *ap = guard.p;
+	ap->d0 = d0; ap->d1 = d1; ap->rd = rd; ap->nv = nv; ap->ne = ne; ap->unary_vertex = unary_vertex;
 	// ---- Lambda structure: diagonal of every vertex + upper block of every edge
 	// (_Lambda_Base.h:1863-1881 builds all block rows/cols first, then :1897 allocates edge blocks)
 	std::vector<std::pair<int64_t, int64_t> > key(ne); // (col, row)
@@ -167,8 +169,13 @@ void assemble_analyze(spp_ctx *ctx, int64_t nv, const int32_t *dim, int64_t ne, 
 		ap->vlist_wave[cls].upload(lwave[cls], s);
 	}
 	SPP_HIP_CHECK(hipStreamSynchronize(s));
-	// the ctx now describes this Lambda (sizes for spp_get_info before spp_analyze is called)
+	// complete: install. The ctx now describes this Lambda (sizes for spp_get_info before spp_analyze is called);
+	// a solve plan analyzed for a DIFFERENT structure is dropped rather than left beside the new sizes
+	if(ctx->mode >= 0 && (ctx->st.nb != st.nb || ctx->st.n != st.n || ctx->st.nnzb != st.nnzb || ctx->st.nvals != st.nvals))
+		ctx->mode = -1;
 	ctx->st.nb = st.nb; ctx->st.n = st.n; ctx->st.nnzb = st.nnzb; ctx->st.nvals = st.nvals;
+	ctx->assemble = ap;
+	guard.p = nullptr;
 }
 
 // --------------------------------------------------------------------------------------------------

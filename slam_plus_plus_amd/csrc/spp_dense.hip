@@ -594,13 +594,15 @@ void potrf_diag_kernel(double *__restrict__ Ablk, int64_t ld, int n_valid, int h
 #pragma unroll
 			for(int t = 0; t < NIT; ++ t) {
 				const int e = (tid - 64) + t * NTH, r = (e & (NB / 2 - 1)) * 2, c = e >> 6;
-				if(e < NP && !(r < 16 && c < 16))
+				// only the upper triangle is an input (16 x 16 tiles on or above the diagonal): the tiles below it
+				// are first ASSIGNED by the G part of the update, never read before -- 44 % of the block not fetched
+				if(e < NP && !(r < 16 && c < 16) && (r >> 4) <= (c >> 4))
 					v[t] = *(const double2*)(Ablk + r + (int64_t)c * ld);
 			}
 #pragma unroll
 			for(int t = 0; t < NIT; ++ t) {
 				const int e = (tid - 64) + t * NTH, r = (e & (NB / 2 - 1)) * 2, c = e >> 6;
-				if(e < NP && !(r < 16 && c < 16)) {
+				if(e < NP && !(r < 16 && c < 16) && (r >> 4) <= (c >> 4)) {
 					T[r + c * TS] = v[t].x;
 					T[r + 1 + c * TS] = v[t].y;
 				}
@@ -857,9 +859,9 @@ void trsv_back_kernel(const double *__restrict__ R, int64_t ld, int64_t k0, int 
 }
 
 
-// Backward substitution as ONE launch: workgroup b owns block row b (128 rows), all workgroups are
-// resident (<= 1024 of them) and run the dependent chain x_last -> ... -> x_0 through global memory
-// instead of through 41 kernel launches. Workgroup b applies x_k to its rows for k = last .. b+1
+// Backward substitution as ONE launch: one workgroup per block row (128 rows), last block row first in dispatch
+// order; the workgroups run the dependent chain x_last -> ... -> x_0 through global memory instead of through 41
+// kernel launches. Workgroup b applies x_k to its rows for k = last .. b+1
 // as the x_k are published (flag[k] == epoch of this solve), then solves its diagonal block with the
 // stored inverse, publishes x_b and exits. Every wait depends only on workgroups with a larger index, which never
 // wait on smaller ones: no cycle. The spin is BOUNDED: on timeout the workgroup raises `err`, publishes
@@ -871,7 +873,10 @@ void trsv_back_chain_kernel(const double *__restrict__ R, int64_t ld, int64_t n,
 	__shared__ double xs[NB];
 	__shared__ double part[2][NB];
 	__shared__ int ok;
-	const int b = blockIdx.x, tid = threadIdx.x, r = tid & (NB - 1), h = tid >> 7;
+	// block row b = nblk - 1 - blockIdx.x: the PRODUCERS (large b) are dispatched first, so a workgroup only ever waits
+	// for workgroups dispatched before it -- progress does not depend on how many workgroups are resident (this kernel
+	// holds a whole CU: more than 256 block rows, or a CU-masked stream, would otherwise park waiters on every CU)
+	const int b = nblk - 1 - (int)blockIdx.x, tid = threadIdx.x, r = tid & (NB - 1), h = tid >> 7;
 	const int64_t r0 = (int64_t)NB * b;
 	// Everything that does not depend on an x_k is fetched ahead of the wait for it: the 64 entries of
 	// this thread's half row of the inverse diagonal block (kept for the whole kernel) and of the next

@@ -184,6 +184,8 @@ struct spp_ctx {
 	spp::AssemblePlan *assemble = nullptr;
 	// staging buffers for the host-pointer entry points
 	spp::DevBuf<double> d_vals, d_rhs;
+	double *h_staging = nullptr; // page-locked host buffer handed out by spp_host_staging()
+	size_t h_staging_cap = 0;    // doubles
 	spp::DevBuf<double> geom_partial; // partial sums of ||dx||^2 (spp_geometry.hip)
 	// profiling
 	spp::PhaseTimer timer;

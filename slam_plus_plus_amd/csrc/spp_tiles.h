@@ -155,8 +155,6 @@ __device__ __forceinline__ void diag_tile_factor_rt(const int TS, double *T, dou
 	//   A mask, bit j: lane feeds row i = c > j in k slot q == (j & 3);  B mask, bit j: not (slot q, column j)
 	const unsigned amask = (0x1111u << q) & ((1u << c) - 1u);
 	const unsigned bmask = ~(((c & 3) == q) ? (1u << c) : 0u);
-#ifdef SPP_TILE_PIVOT_PER_STEP
-	// round-1 formulation: the two scalars of the NEXT pivot are read (4 v_readlane_b32) between every two MFMAs
 	double p = readlane_f64(acc[0], 0);
 	SPP_TILE_STAMP(1, p);
 	double r0 = __builtin_amdgcn_rcp(p);
@@ -171,8 +169,16 @@ __device__ __forceinline__ void diag_tile_factor_rt(const int TS, double *T, dou
 		const double aop = and_f64(-rowv * pinv, aw); // A[i][k]: -W[j][i] / p_j for rows i > j
 		const double bop = and_f64(rowv, bw);         // B[k][c]:  W[j][c], column j dropped
 		// scalars of the next pivot: W[j][j+1] and W[j+1][j+1] before this pivot's update
+#ifndef SPP_TILE_BPERMUTE
 		const double wj = readlane_f64(rowv, (j + 1) | (qj << 4));
 		const double wd = readlane_f64(diag, (j + 1) | (((j + 1) & 3) << 4));
+#else
+		// experiment: broadcast into VGPRs (ds_bpermute), issued before the MFMA and consumed in its shadow. Measured
+		// 5 700 instead of 5 400 cycles per tile: the crossbar round trip plus fma -> rcp -> Newton -> scale is longer
+		// than the MFMA it was meant to hide under. Kept for reference.
+		const double wj = bcast_f64(rowv, (j + 1) | (qj << 4));
+		const double wd = bcast_f64(diag, (j + 1) | (((j + 1) & 3) << 4));
+#endif
 		__builtin_amdgcn_sched_barrier(0);
 		acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
 		__builtin_amdgcn_sched_barrier(0);
@@ -187,52 +193,6 @@ __device__ __forceinline__ void diag_tile_factor_rt(const int TS, double *T, dou
 		__builtin_amdgcn_sched_barrier(0);
 		SPP_PIVOT_STAMP(j, p);
 	}
-#else
-	// Pivots in blocks of four. The readlanes of the round-1 formulation sat BETWEEN every two dependent MFMAs
-	// (they read the accumulator the previous MFMA writes): 235 of the 340 cycles per pivot. Here the ten
-	// entries of the 4 x 4 diagonal block are read ONCE per block (20 v_readlane_b32 behind the last MFMA of the
-	// previous block) and every lane eliminates that block on its own in uniform registers -- the same operations
-	// in the same order and rounding as the MFMAs apply to those entries (a = -(w_ji / p_j) rounded, then one fma) --
-	// which yields the four reciprocal pivots ahead of time; the elimination of block entries and the reciprocals of
-	// pivots 1..3 run in the shadow of the MFMAs. Between two MFMAs of a block only the operand scaling is left.
-	double p = 0;
-#pragma unroll
-	for(int b = 0; b < 4; ++ b) {
-		double d[4][4];
-#pragma unroll
-		for(int u = 0; u < 4; ++ u)
-#pragma unroll
-			for(int v = u; v < 4; ++ v)
-				d[u][v] = readlane_f64(acc[b], (4 * b + v) | (u << 4)); // W[4b+u][4b+v]: lane (c = 4b+v, q = u), register b
-		if(b == 0)
-			SPP_TILE_STAMP(1, d[0][0]);
-#pragma unroll
-		for(int u = 0; u < 4; ++ u) {
-			const int j = 4 * b + u;
-			if(j == 15)
-				break; // the last pivot updates nothing
-			p = d[u][u];
-			const double r0 = __builtin_amdgcn_rcp(p);
-			const double pinv = r0 * (2.0 - p * r0); // v_rcp_f64 + one Newton step
-			const int aw = sbit(amask, j), bw = sbit(bmask, j);
-			const double rowv = acc[b];
-			const double aop = and_f64(-rowv * pinv, aw); // A[i][k]: -W[j][i] / p_j for rows i > j
-			const double bop = and_f64(rowv, bw);         // B[k][c]:  W[j][c], column j dropped
-			__builtin_amdgcn_sched_barrier(0);
-			acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
-			__builtin_amdgcn_sched_barrier(0);
-			// in the MFMA's shadow: the rest of the diagonal block after this pivot
-#pragma unroll
-			for(int v = u + 1; v < 4; ++ v) {
-				const double a = -d[u][v] * pinv;
-#pragma unroll
-				for(int w = v; w < 4; ++ w)
-					d[v][w] = __builtin_fma(a, d[u][w], d[v][w]);
-			}
-			SPP_PIVOT_STAMP(j, p);
-		}
-	}
-#endif
 	SPP_TILE_STAMP(2, acc[0] + acc[1] + acc[2] + acc[3] + p);
 	// the lanes with (c & 3) == q hold the diagonal p_c in acc[c >> 2]; 1 / sqrt(p_i) is exchanged via dinv
 	double pc = acc[0];

@@ -108,7 +108,7 @@ def load_matrix_market(path_mtx, path_bla):
 # --------------------------------------------------------------------------------------------------
 _SE2_EDGE = {"EDGE_SE2", "EDGE2", "EDGE", "ODOMETRY"}
 _SE2_VERTEX = {"VERTEX_SE2", "VERTEX2", "VERTEX"}
-_SE3_EDGE = {"EDGE3", "EDGE_SE3"}
+_SE3_EDGE = {"EDGE3", "EDGE_SE3", "EDGE3:AXISANGLE", "EDGE_SE3:AXISANGLE"}
 _SE3_VERTEX = {"VERTEX3", "VERTEX_SE3"}
 
 
@@ -121,7 +121,8 @@ def _upper_to_full(u, d):
 def load_graph(path):
     """Parse the tokens the BASELINE configs use. Returns a dict of numpy arrays:
       se2_vertices (id, x, y, theta), se2_edges (i, j, dx, dy, dtheta) + se2_info (3x3 each)
-      se3_vertices (id, 6), se3_edges (i, j, 6) + se3_info (6x6 each)
+      se3_vertices (id, 6: t + roll pitch yaw as in the file), se3_edges (i, j, t, AXIS-ANGLE: the parser's conversion
+      of roll-pitch-yaw is applied to EDGE3 / EDGE_SE3, EDGE3:AXISANGLE is taken as it stands) + se3_info (6x6 each)
       cams (id, 6 pose + 5 intrinsics), points (id, xyz), projections (point id, cam id, u, v) + proj_info (2x2)
     2D information is given as the 6 upper-triangular values in the order of
     ParsePrimitives.h (xx xy yy tt xt yt for the classic EDGE2 format is NOT assumed: the g2o
@@ -142,7 +143,12 @@ def load_graph(path):
             elif tok in _SE3_VERTEX and len(a) >= 7:
                 out["se3_vertices"].append([float(x) for x in a[:7]])
             elif tok in _SE3_EDGE and len(a) >= 29:
-                out["se3_edges"].append([float(x) for x in a[:8]])
+                m = [float(x) for x in a[:8]]
+                if not tok.endswith(":AXISANGLE"):
+                    # roll-pitch-yaw -> axis-angle exactly as the parser does (ParsePrimitives.h:504-519): Q = Rz Ry Rx
+                    from scipy.spatial.transform import Rotation
+                    m[5:8] = Rotation.from_euler("ZYX", [m[7], m[6], m[5]]).as_rotvec().tolist()
+                out["se3_edges"].append(m)
                 out["se3_info"].append(_upper_to_full([float(x) for x in a[8:29]], 6))
             elif tok == "VERTEX_CAM" and len(a) >= 13:
                 out["cams"].append([float(x) for x in a[:13]])
@@ -373,3 +379,67 @@ def ba_linearize(cams, intr, points, obs, cam_id=None, pt_id=None):
                    J0=np.ascontiguousarray(J0.transpose(0, 2, 1)).reshape(no, 12),
                    J1=np.ascontiguousarray(PR.transpose(0, 2, 1)).reshape(no, 6),
                    Om=np.tile(np.eye(2).ravel(), (no, 1)), r=obs[:, 2:4] - uv, unary_vertex=0, damping=0.0)
+
+
+def problem_from_graph(path):
+    """Graph file -> hot-path inputs (synth.Problem) at the file's initial estimate, plus a short description.
+    2D / 3D pose graphs without VERTEX lines are initialized the way the reference's parse loop does it
+    (CEdgePose2D / CEdgePose3D constructors: an unseen second vertex becomes first (+) measurement, in file order);
+    BA files use the reference's VERTEX_CAM convention (camera-to-world in the file)."""
+    from scipy.spatial.transform import Rotation
+    g = load_graph(path)
+    if g["projections"].size:
+        cams_f, pts_f, proj = g["cams"], g["points"], g["projections"]
+        q = Rotation.from_quat(cams_f[:, 4:8]).inv()          # the parser's inversion (ParsePrimitives.h:886-905)
+        cams = np.concatenate([q.apply(-cams_f[:, 1:4]), q.as_rotvec()], axis=1)
+        ids = np.concatenate([cams_f[:, 0], pts_f[:, 0]]).astype(np.int64)
+        nv = int(ids.max()) + 1
+        cam_id, pt_id = cams_f[:, 0].astype(np.int64), pts_f[:, 0].astype(np.int64)
+        cam_index = np.full(nv, -1, dtype=np.int64)
+        cam_index[cam_id] = np.arange(cam_id.size)
+        pt_index = np.full(nv, -1, dtype=np.int64)
+        pt_index[pt_id] = np.arange(pt_id.size)
+        obs = np.stack([cam_index[proj[:, 1].astype(np.int64)].astype(np.float64),     # ba_linearize: cam pt u v
+                        pt_index[proj[:, 0].astype(np.int64)].astype(np.float64), proj[:, 2], proj[:, 3]], axis=1)
+        prob = ba_linearize(cams, cams_f[:, 8:13], pts_f[:, 1:4], obs, cam_id=cam_id, pt_id=pt_id)
+        prob["Om"] = np.ascontiguousarray(g["proj_info"]).reshape(-1, 4)
+        prob["nc"], prob["npts"] = cam_id.size, pt_id.size
+        return prob, "BA graph file (%d cameras, %d points, %d observations)" % (cam_id.size, pt_id.size, obs.shape[0])
+    if g["se3_edges"].size:
+        e = g["se3_edges"]
+        n = int(e[:, :2].max()) + 1
+        poses = np.zeros((n, 6))
+        seen = np.zeros(n, dtype=bool)
+        for v in g["se3_vertices"].reshape(-1, 7):  # VERTEX3: t + roll pitch yaw (ParsePrimitives.h:741-797)
+            poses[int(v[0])] = np.concatenate([v[1:4], Rotation.from_euler("ZYX", [v[6], v[5], v[4]]).as_rotvec()])
+            seen[int(v[0])] = True
+        if not seen.any():
+            seen[int(e[0, 0])] = True
+        for a, b, *z in e:
+            a, b = int(a), int(b)
+            if seen[a] and not seen[b]:
+                poses[b] = se3_plus(poses[a:a + 1], np.asarray(z)[None, :])[0]
+                seen[b] = True
+        if not seen.all():
+            raise ValueError("3D pose graph: %d poses are not reachable through forward edges" % int((~seen).sum()))
+        return se3_linearize(poses, e, g["se3_info"]), "3D pose graph file (%d poses, %d edges)" % (n, e.shape[0])
+    if g["se2_edges"].size:
+        e = g["se2_edges"]
+        n = int(e[:, :2].max()) + 1
+        poses = np.zeros((n, 3))
+        seen = np.zeros(n, dtype=bool)
+        for v in g["se2_vertices"].reshape(-1, 4):
+            poses[int(v[0])] = v[1:4]
+            seen[int(v[0])] = True
+        if not seen.any():
+            seen[int(e[0, 0])] = True
+        for a, b, dx, dy, dt in e:
+            a, b = int(a), int(b)
+            if seen[a] and not seen[b]:
+                c, s = np.cos(poses[a, 2]), np.sin(poses[a, 2])
+                poses[b] = [poses[a, 0] + c * dx - s * dy, poses[a, 1] + s * dx + c * dy, poses[a, 2] + dt]
+                seen[b] = True
+        if not seen.all():
+            raise ValueError("2D pose graph: %d poses are not reachable through forward edges" % int((~seen).sum()))
+        return se2_linearize(poses, e, g["se2_info"]), "2D pose graph file (%d poses, %d edges)" % (n, e.shape[0])
+    raise ValueError("no edges of a known type in %s" % path)

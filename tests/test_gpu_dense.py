@@ -98,3 +98,24 @@ def test_potrf_reports_not_posdef(hip_ctx):
     st = hip_ctx.lib.spp_dense_potrf_upper(hip_ctx.h, dA.ptr, n, n)
     dA.free()
     assert st == api.SPP_NOT_POSDEF
+
+
+def test_backward_chain_with_more_block_rows_than_compute_units(hip_ctx):
+    """n = 33 000: 258 block rows of 128, more than the 256 CUs -- and the single-launch backward substitution holds a
+    whole CU per workgroup, so not all of its workgroups can be resident. Progress must not depend on residency
+    (block row = last minus blockIdx: producers are dispatched before their consumers). Diagonal + rank-8 matrix
+    (8.7 GB); checked through the residual."""
+    n = 33000
+    rng = np.random.default_rng(5)
+    V = rng.standard_normal((n, 8))
+    A = V @ V.T
+    A[np.diag_indices(n)] += 4.0 + rng.random(n)
+    b = rng.standard_normal(n)
+    dA = api.DeviceArray.from_host(hip_ctx, A.reshape(-1))   # symmetric: row-major == column-major
+    db = api.DeviceArray.from_host(hip_ctx, b)
+    st = hip_ctx._check(hip_ctx.lib.spp_dense_posv(hip_ctx.h, dA.ptr, n, n, db.ptr))
+    assert st == 0
+    x = db.download()
+    dA.free(); db.free()
+    res = np.linalg.norm(A @ x - b) / np.linalg.norm(b)
+    assert res < 1e-12, res
