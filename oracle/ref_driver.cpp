@@ -6,7 +6,7 @@
  * the reference sources where they lie under /root/reference by
  * oracle/Makefile (outputs only into oracle/_ref/). It exists so that
  *   (1) the CPU restatement in oracle/spp_oracle.c can be pinned against the
- *       reference itself (tests/test_oracle_vs_ref.py), and
+ *       reference itself (tests/test_oracle_golden.py), and
  *   (2) bench.py can time the reference CPU path beside the HIP path
  *       (cpu_baseline.kind == "reference").
  * Nothing here is copied from the reference: it only *calls* its public API

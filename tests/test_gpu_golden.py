@@ -27,7 +27,7 @@ def test_hip_solution_matches_reference_golden(name):
     x = eta.copy()
     assert s.Solve_PosDef_Blocky(lam, x)
     stride = int(g["dx_stride"])
-    tol = max(1e-10, 25 * float(g["spread"]))
+    tol = max(1e-10, 4 * float(g["spread"]))
     for key in g.files:
         if key.startswith("dx_") and key != "dx_stride":
             assert _rel(x[::stride], g[key]) < tol, (key, _rel(x[::stride], g[key]), tol)
