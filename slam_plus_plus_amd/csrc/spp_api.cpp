@@ -134,6 +134,7 @@ int spp_free_memory(spp_ctx *ctx)
 	ctx->dense.flags.release();
 	ctx->dense.epoch = 0;
 	ctx->dense.sync.release();
+	ctx->dense.fuse_cnt.release();
 	ctx->dense.sync_epoch = 0;
 	ctx->d_vals.release();
 	ctx->d_rhs.release();

@@ -338,19 +338,26 @@ __global__ void flag_wait_kernel(FlagWait fw)
 		flag_spin(fw);
 }
 
-template <int BM, int BN, int WM, int WN, int MODE, int ATRI = 0>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64)
-void gemm_tn_staged_kernel(int64_t M, int64_t N, int K, const double *__restrict__ A, int64_t lda,
-	const double *B, int64_t ldb, double *C, int64_t ldc, int upper_only)
+// signal one flag, then wait for another: the chain stream's "row panel k is complete" and "bulk update k-1 is
+// complete" sit next to each other in its order -- one launch instead of two
+__global__ void flag_signal_wait_kernel(int *flag, int value, FlagWait fw)
+{
+	if(threadIdx.x == 0) {
+		__hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		flag_spin(fw);
+	}
+}
+
+// one BM x BN tile of C at (m0, n0) by the first (BM / WM) * (BN / WN) waves of the workgroup (the body shared by
+// gemm_tn_staged_kernel and the fused update + diagonal-block kernel); fs_lds: (BM + BN) * FS_STRIDE doubles
+template <int BM, int BN, int WM, int WN, int MODE, int ATRI>
+__device__ __forceinline__ void gemm_tn_staged_tile(const int64_t m0, const int64_t n0, int64_t M, int64_t N,
+	const double *__restrict__ A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, double *fs_lds)
 {
 	constexpr bool a_upper_tri = ATRI != 0; // A(k, m) = 0 for k > m, BM covers all of A's columns (m0 == 0)
 	constexpr int NWM = BM / WM, NWN = BN / WN, NT = NWM * NWN * 64;
 	constexpr int TA = WM / 16, TB = WN / 16;
-	extern __shared__ double fs_lds[];
 	double *As = fs_lds, *Bs = fs_lds + BM * FS_STRIDE;
-	const int64_t m0 = (int64_t)blockIdx.x * BM, n0 = (int64_t)blockIdx.y * BN;
-	if(upper_only && m0 >= n0 + BN)
-		return;
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int wm = (wave % NWM) * WM, wn = (wave / NWM) * WN;
 	const int l15 = lane & 15, l4 = lane >> 4;
@@ -432,6 +439,18 @@ void gemm_tn_staged_kernel(int64_t M, int64_t N, int K, const double *__restrict
 					C[m + n * ldc] = (MODE == 0) ? -acc[b][a][r] : acc[b][a][r];
 			}
 		}
+}
+
+template <int BM, int BN, int WM, int WN, int MODE, int ATRI = 0>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64)
+void gemm_tn_staged_kernel(int64_t M, int64_t N, int K, const double *__restrict__ A, int64_t lda,
+	const double *B, int64_t ldb, double *C, int64_t ldc, int upper_only)
+{
+	extern __shared__ double fs_lds[];
+	const int64_t m0 = (int64_t)blockIdx.x * BM, n0 = (int64_t)blockIdx.y * BN;
+	if(upper_only && m0 >= n0 + BN)
+		return;
+	gemm_tn_staged_tile<BM, BN, WM, WN, MODE, ATRI>(m0, n0, M, N, A, lda, B, ldb, C, ldc, fs_lds);
 }
 
 template <int BM, int BN, int WM, int WN, int MODE, int ATRI = 0>
@@ -552,11 +571,9 @@ __device__ __forceinline__ void lds_barrier()
 	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-__global__ __launch_bounds__(POTRF_THREADS)
-void potrf_diag_kernel(double *__restrict__ Ablk, int64_t ld, int n_valid, int has_rhs,
-	double *__restrict__ tinv, int *__restrict__ info, int64_t k0)
+__device__ __forceinline__ void potrf_diag_body(double *__restrict__ Ablk, int64_t ld, int n_valid, int has_rhs,
+	double *__restrict__ tinv, int *__restrict__ info, int64_t k0, double *sm)
 {
-	extern __shared__ double sm[];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	SPP_STAMP(0, 0);
 	double *T = sm;                  // NB x NB image, stride TS
@@ -798,6 +815,96 @@ void potrf_diag_kernel(double *__restrict__ Ablk, int64_t ld, int n_valid, int h
 	if(rhs_col >= 0 && tid < n_valid)
 		Ablk[tid + (int64_t)rhs_col * ld] = yv[tid];
 	SPP_STAMP(52, 0);
+}
+
+__global__ __launch_bounds__(POTRF_THREADS)
+void potrf_diag_kernel(double *__restrict__ Ablk, int64_t ld, int n_valid, int has_rhs,
+	double *__restrict__ tinv, int *__restrict__ info, int64_t k0)
+{
+	extern __shared__ double sm[];
+	potrf_diag_body(Ablk, ld, n_valid, has_rhs, tinv, info, k0, sm);
+}
+
+
+// --------------------------------------------------------------------------------------------------
+// Fused chain kernel: trailing update from ONE row panel + factorization of the next diagonal block.
+//
+// The chain of the factorization used to run  tile row (20 us) -> potrf_diag (30 us) -> panel solve (6 us)  one after
+// the other, although potrf_diag needs ONE 128 x 128 tile of the tile row. Here both are one launch:
+//   region  C = rows [r0, r0 + M) x cols [r0, r0 + N) of the matrix (upper part), panel P = 128 rows at kp0
+//   blockIdx.x in [0, nA)  32 x 32 sub-tiles of the region's FIRST 128 x 128 tile (upper ones), four waves each (the
+//                          other twelve leave at once); each signals a counter behind an agent-scope release
+//   blockIdx.x == nA       (do_potrf) waits for the nA signals -- producers have smaller block ids, are dispatched
+//                          first and wait for nobody; the spin is bounded all the same --, acquires, factors the tile
+//                          (potrf_diag_body) while
+//   blockIdx.x  > nA       the rest of the region is updated in 64 x 64 blocks (16 waves, operands fully staged).
+// LDS is sized for the factorization (143 KB): one workgroup per CU. The panel solve of the next step follows as its
+// own launch (it needs the whole tile row AND the factor).
+// --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(POTRF_THREADS)
+void update_potrf_kernel(int64_t M, int64_t N, const double *P, int64_t ld, double *C, int nA, int do_potrf,
+	int n_valid, int has_rhs, double *tinv, int *info, int64_t k0_next, int *counter, int *abort, long long timeout_ticks)
+{
+	extern __shared__ double sm[];
+	const int b = (int)blockIdx.x, tid = threadIdx.x;
+	if(b < nA) {
+		if(tid >= 256)
+			return; // four waves per sub-tile (a barrier does not wait for waves that have ended)
+		// sub-tile b -> (i, j), i <= j, of the first tile, columns first
+		const int ti = (int)((((M < NB) ? M : NB) + 31) >> 5);
+		int j = 0, rem = b;
+		for(;; ++ j) {
+			const int cnt = ((j < ti - 1) ? j : ti - 1) + 1;
+			if(rem < cnt)
+				break;
+			rem -= cnt;
+		}
+		gemm_tn_staged_tile<32, 32, 16, 16, 0, 0>((int64_t)rem * 32, (int64_t)j * 32, M, N, P, ld, P, ld, C, ld, sm);
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads();
+		if(tid == 0) {
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			__hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		return;
+	}
+	if(do_potrf && b == nA) {
+		__shared__ int go;
+		if(tid == 0) {
+			const long long t0 = wall_clock64();
+			int ok = 1;
+			for(int it = 0; __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nA; ++ it) {
+				if((it & 15) == 15) {
+					if(__hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+						ok = 0;
+						break;
+					}
+					if(wall_clock64() - t0 > timeout_ticks) {
+						__hip_atomic_store(abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						ok = 0;
+						break;
+					}
+				}
+				__builtin_amdgcn_s_sleep(1);
+			}
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			go = ok;
+		}
+		__syncthreads();
+		if(!go)
+			return;
+		potrf_diag_body(C, ld, n_valid, has_rhs, tinv, info, k0_next, sm);
+		return;
+	}
+	// the rest of the region in 64 x 64 blocks, block columns first
+	const int64_t q = b - nA - (do_potrf ? 1 : 0);
+	const int64_t nbi = (M + 63) >> 6;
+	const int64_t bi = q % nbi, bj = q / nbi;
+	if(bi > bj || (bi < 2 && bj < 2))
+		return; // strictly below the diagonal, or part of the first tile
+	gemm_tn_staged_tile<64, 64, 16, 16, 0, 0>(bi * 64, bj * 64, M, N, P, ld, P, ld, C, ld, sm);
 }
 
 // backward substitution step for block column k (rows/cols k0 .. k0 + NB):
@@ -1188,10 +1295,11 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 		SPP_HIP_CHECK(hipEventRecord(evA, s));
 		SPP_HIP_CHECK(hipStreamWaitEvent(s2, evA, 0));
 	}
+	int64_t pend_sig = -1; // flags only: "row panel pend_sig is complete" not yet enqueued (merged with the next wait on s)
 	auto record_a = [&](int64_t k) { // row panel k is complete on s
 		step_a = k;
 		if(use_flags)
-			flag_signal(s, dw.sync.p + 2 * k, ep);
+			pend_sig = k; // enqueued by flush_wait_b(), together with the wait that follows it on the chain stream
 		else
 			SPP_HIP_CHECK(hipEventRecord(evA, s));
 	};
@@ -1209,6 +1317,10 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 			SPP_HIP_CHECK(hipEventRecord(evB, s2));
 	};
 	auto wait_b_kernel = [&](hipStream_t st) { // a wait of its own (event or one-wave kernel)
+		if(use_flags && st == s && pend_sig >= 0) { // a deferred panel signal goes first (never left behind a wait)
+			flag_signal(s, dw.sync.p + 2 * pend_sig, ep);
+			pend_sig = -1;
+		}
 		if(use_flags)
 			flag_wait(ctx, st, dw.sync.p + 2 * step_b + 1, ep);
 		else
@@ -1220,11 +1332,15 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 		else
 			SPP_HIP_CHECK(hipStreamWaitEvent(s, evB, 0));
 	};
-	auto flush_wait_b = [&]() { // no tile-row kernel took the deferred wait: a wait kernel does
-		if(need_wait_b >= 0) {
+	auto flush_wait_b = [&]() { // everything deferred on the chain stream: the panel signal, the wait for a bulk update, or both in one launch
+		if(need_wait_b >= 0 && pend_sig >= 0)
+			hipLaunchKernelGGL(flag_signal_wait_kernel, dim3(1), dim3(64), 0, s, dw.sync.p + 2 * pend_sig, ep,
+				make_flag_wait(ctx, dw.sync.p + 2 * need_wait_b + 1, ep));
+		else if(need_wait_b >= 0)
 			flag_wait(ctx, s, dw.sync.p + 2 * need_wait_b + 1, ep);
-			need_wait_b = -1;
-		}
+		else if(pend_sig >= 0)
+			flag_signal(s, dw.sync.p + 2 * pend_sig, ep);
+		need_wait_b = pend_sig = -1;
 	};
 	static int64_t trsm_shared_above = -1;
 	if(trsm_shared_above < 0) {
@@ -1248,10 +1364,50 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 		panel_tri = e ? atoi(e) : 0;
 	}
 	bool row_pending = false; // the remainder of tile row k (stream ctx->dense.row) has to finish before panel k
-	auto potrf_and_panel = [&](hipStream_t st, int64_t k) {
+	// Fused chain kernel (update_potrf_kernel): the update of a row region from panel kp and the factorization of the
+	// region's first diagonal block (step kn) in one launch; the panel solve of step kn follows as its own launch.
+	static int fused = -1;
+	if(fused < 0) {
+		const char *e = getenv("SPP_FUSED"); // 0: tile row / update, potrf_diag and panel solve as three launches (round 1)
+		fused = e ? atoi(e) : 1;
+	}
+	if(fused) {
+		static bool fattr = false;
+		if(!fattr) {
+			SPP_HIP_CHECK(hipFuncSetAttribute((const void*)update_potrf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+				POTRF_LDS_DOUBLES * (int)sizeof(double)));
+			fattr = true;
+		}
+		if(dw.fuse_cnt.cap < (size_t)(nsteps + 2))
+			dw.fuse_cnt.reserve((size_t)(nsteps + 2));
+		SPP_HIP_CHECK(hipMemsetAsync(dw.fuse_cnt.p, 0, (size_t)(nsteps + 2) * sizeof(int), s));
+	}
+	static_assert(POTRF_LDS_DOUBLES >= (64 + 64) * FS_STRIDE, "the fused kernel's LDS is sized by the factorization");
+	// region rows [r0, r0 + m) x cols [r0, ncols), panel rows at kp0; potrf of step kn when kn >= 0
+	auto fused_update_potrf = [&](int64_t r0, int64_t m, int64_t kp0, int64_t kn) {
+		const int64_t N = ncols - r0;
+		if(m <= 0 || N <= 0)
+			return false;
+		const int64_t md = std::min<int64_t>(NB, m), nd = std::min<int64_t>(NB, N);
+		const int ti = (int)((md + 31) / 32), tj = (int)((nd + 31) / 32);
+		int nA = 0;
+		for(int j = 0; j < tj; ++ j)
+			nA += std::min(j, ti - 1) + 1;
+		const int64_t nbi = (m + 63) / 64, nbj = (N + 63) / 64;
+		const int do_potrf = kn >= 0 ? 1 : 0;
+		const int64_t kn0 = (kn >= 0 ? kn : 0) * NB;
+		const int n_valid = (int)((n - kn0 < NB) ? (n - kn0) : NB);
+		hipLaunchKernelGGL(update_potrf_kernel, dim3((unsigned)(nA + do_potrf + nbi * nbj)), dim3(POTRF_THREADS),
+			POTRF_LDS_DOUBLES * sizeof(double), s, m, N, d_A + kp0 + r0 * ld, ld, d_A + r0 + r0 * ld, nA, do_potrf,
+			n_valid, (has_rhs && n_valid < NB) ? 1 : 0, dw.tinv_all.p + (size_t)(kn >= 0 ? kn : 0) * NB * NB, dw.info.p, kn0,
+			dw.fuse_cnt.p + (kn >= 0 ? kn : nsteps + 1), dw.info.p + 2, (long long)(500.0 * 1e5));
+		return true;
+	};
+	auto potrf_and_panel = [&](hipStream_t st, int64_t k, bool potrf_done = false) {
 		const int64_t k0 = k * NB;
 		const int n_valid = (int)((n - k0 < NB) ? (n - k0) : NB);
 		double *tinv = ctx->dense.tinv_all.p + (size_t)k * NB * NB;
+		if(!potrf_done)
 		hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(POTRF_THREADS), POTRF_LDS_DOUBLES * sizeof(double), st,
 			d_A + k0 + k0 * ld, ld, n_valid, (has_rhs && n_valid < NB) ? 1 : 0, tinv, ctx->dense.info.p, k0);
 		if(row_pending) {
@@ -1343,6 +1499,11 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 	static int64_t single_below = -1;
 	static int single_tile = 64;
 	static int64_t single_mixed_above = 1280;
+	static int64_t fused_below = -1;
+	if(fused_below < 0) {
+		const char *e = getenv("SPP_FUSED_BELOW"); // single-stream steps with at most this many trailing rows use the fused kernel
+		fused_below = e ? atol(e) : (int64_t(1) << 40);
+	}
 	if(single_below < 0) {
 		const char *e = getenv("SPP_SINGLE_BELOW");
 		single_below = e ? atol(e) : 2560;
@@ -1362,6 +1523,13 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 				bulk_pending = false;
 			}
 			const double *P = d_A + k0 + c1 * ld;
+			if(fused && rows - c1 <= fused_below && k + 1 < nsteps && rows - c1 >= NB) {
+				// one launch: every trailing tile <- panel k, the next diagonal block factored as soon as ITS tile is done
+				fused_update_potrf(c1, rows - c1, k0, k + 1);
+				potrf_and_panel(s, k + 1, true);
+				++ k;
+				continue;
+			}
 			if(rows - c1 >= single_mixed_above) { // the fine-grained MFMA kernel wins from ~10 tile rows on
 				dom_begin(ctx);
 				const bool big = dense_gemm_tn_sub(ctx, rows - c1, ncols - c1, NB, P, ld, P, ld, d_A + c1 + c1 * ld, ld, true);
@@ -1395,6 +1563,7 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 		}
 		const int64_t cb = (npan == 2) ? c3 : c2;
 		const bool have_bulk = rows - cb > 0 && cb < ncols;
+		bool fused_done = false; // potrf of step k+1 already done by the fused kernel
 		if(!early || !have_bulk) {
 			tile_row(c1, k0, 1);
 			flush_wait_b();
@@ -1434,6 +1603,10 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 					SPP_HIP_CHECK(hipEventRecord(ctx->dense.ev_row, s3));
 					row_pending = true;
 					launch_gemm_staged<32, 32, 16, 16, 0>(s, NB, NB, NB, Pa, ld, Pa, ld, d_A + c1 + c1 * ld, ld, true);
+				} else if(fused && npan == 1 && k + 1 < nsteps && rows - c1 >= NB) {
+					flush_wait_b();
+					fused_update_potrf(c1, NB, k0, k + 1); // tile row k+1 <- panel k, potrf(k+1) inside
+					fused_done = true;
 				} else
 					tile_row(c1, k0, 1);
 			}
@@ -1441,7 +1614,7 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 		flush_wait_b();
 		// next pair's first diagonal block + row panel overlaps the bulk update
 		if(k + npan < nsteps)
-			potrf_and_panel(s, k + npan);
+			potrf_and_panel(s, k + npan, fused_done);
 		k += npan;
 	}
 	if(bulk_pending) {

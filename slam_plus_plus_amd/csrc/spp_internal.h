@@ -145,6 +145,7 @@ struct DenseWork {
 	// device-flag hand-offs between the chain stream and the bulk stream (dense_factor_steps_enqueue):
 	// sync[2 k] = row panel k complete, sync[2 k + 1] = bulk update k complete, as the epoch of the factorization
 	DevBuf<int> sync;
+	DevBuf<int> fuse_cnt;          // per step: sub-tiles of the next diagonal tile finished (update_potrf_kernel)
 	int sync_epoch = 0;
 	int sync_state = 0;            // 0: not tested on this stream, 1: the streams run concurrently, -1: disabled
 	hipStream_t sync_stream = nullptr; // the ctx stream the self-test ran against

@@ -27,10 +27,15 @@ def test_hip_solution_matches_reference_golden(name):
     x = eta.copy()
     assert s.Solve_PosDef_Blocky(lam, x)
     stride = int(g["dx_stride"])
-    tol = max(1e-10, 4 * float(g["spread"]))
-    for key in g.files:
-        if key.startswith("dx_") and key != "dx_stride":
-            assert _rel(x[::stride], g[key]) < tol, (key, _rel(x[::stride], g[key]), tol)
+    if name.startswith(("ba", "lady")):
+        # LM-damped BA systems (cond ~1e5): north_star's bound against every reference backend directly
+        for key in g.files:
+            if key.startswith("dx_") and key != "dx_stride":
+                assert _rel(x[::stride], g[key]) < 1e-10, (key, _rel(x[::stride], g[key]))
+    # every case: at most 4x less accurate than the reference is itself, both measured against the refined solution
+    # of the same Lambda (tests/parity.py; on the pose graphs the reference's own backends are 1e-9..1e-7 away from it)
+    import parity
+    parity.check_against_reference(x, g, lam, eta)
 
 
 def test_venice_full_size_properties():

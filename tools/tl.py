@@ -7,7 +7,7 @@ idx = [i for i, k in enumerate(ks) if "set_info_kernel" in k[2]]
 i0 = idx[-2]; i1 = idx[-1]; t0 = ks[i0][0]
 short = {"potrf_diag": "POTRF", "gemm_tn_staged_kernel<128, 16": "panel", "gemm_tn_staged_kernel<64, 64": "upd64",
          "gemm_tn_staged_kernel<32, 32": "upd32", "gemm_tn_kernel<128, 128": "BULK128", "gemm_tn_kernel<64": "bulk64",
-         "gemm_tn_mixed": "BULKMIX", "flag_wait": "wait", "flag_signal": "sig"}
+         "gemm_tn_mixed": "BULKMIX", "flag_wait": "wait", "flag_signal_wait": "sigwait", "flag_signal": "sig", "update_potrf": "FUSED"}
 prev = None
 for k in ks[i0:i1]:
     nm = k[2].replace("void spp::", "").replace("spp::", "")
