@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <numeric>
 #include <string.h>
+#include <stdlib.h>
 
 namespace spp {
 
@@ -402,7 +403,12 @@ void build_schur_plan(spp_ctx *ctx, bool sparse_S, bool mis)
 	// on Venice) then stay in the L2 of the XCD that works through the tile (the kernel hands each XCD
 	// one contiguous range of items).
 	{
-		const int64_t TB = 4, ntile = (nc + TB - 1) / TB;
+		static int64_t tb_env = -1;
+		if(tb_env < 0) {
+			const char *e = getenv("SPP_SACC_TILE"); // cameras per side of an item tile (1 = plain row-major block order)
+			tb_env = e ? std::max<int64_t>(1, atol(e)) : 4;
+		}
+		const int64_t TB = tb_env, ntile = (nc + TB - 1) / TB;
 		std::vector<int32_t> perm(item_blk.size());
 		for(size_t q = 0; q < perm.size(); ++ q)
 			perm[q] = (int32_t)q;

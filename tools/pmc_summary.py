@@ -1,7 +1,7 @@
 """Fold two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, --kernel-trace only) into
 profiles/pmc_traffic.json and a per-kernel csv.
 
-    python tools/pmc_summary.py <fetch_dir> <write_dir> <workload> <kernel substring> [out.json] [out.csv]
+    python tools/pmc_summary.py <fetch_dir> <write_dir> <workload> <kernel substring> [out.json] [out.csv] [round tag]
 
 bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: FETCH_SIZE / WRITE_SIZE are in KiB, and on
 gfx950 FETCH_SIZE reports half of the 16-B/lane streaming reads (MI355X_MICROARCH.md, HBM section).
@@ -30,6 +30,7 @@ def main():
     fdir, wdir, workload, sub = sys.argv[1:5]
     out_json = sys.argv[5] if len(sys.argv) > 5 else "profiles/pmc_traffic.json"
     out_csv = sys.argv[6] if len(sys.argv) > 6 else None
+    source = sys.argv[7] if len(sys.argv) > 7 else "an earlier profiling run"
     f, w = per_kernel(fdir, "FETCH_SIZE"), per_kernel(wdir, "WRITE_SIZE")
     rows = []
     for k in sorted(set(f) | set(w), key=lambda k: -(2 * f.get(k, [0, 0])[1] + w.get(k, [0, 0])[1])):
@@ -48,7 +49,7 @@ def main():
     js = json.load(open(out_json)) if os.path.exists(out_json) else {}
     js[workload] = {
         "kernel": k[0], "bytes_per_launch": k[5], "fetch_size_kb_avg": k[2], "write_size_kb_avg": k[4],
-        "launches_profiled": k[1],
+        "launches_profiled": k[1], "source": "round " + source,
         "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (with --kernel-trace only); "
                "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 FETCH_SIZE reports half of 16-B/lane streaming reads, "
                "MI355X_MICROARCH.md HBM section); tools/pmc_summary.py"}
