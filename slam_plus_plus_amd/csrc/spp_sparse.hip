@@ -7,7 +7,7 @@
 //   Permute_UpperTriangular_To              src/slam/BlockMatrix.cpp:8183        -> index lists, no data moved
 //   Build_EliminationTree / n_Build_EReach  src/slam/BlockMatrix.cpp:9403,9453   -> etree + postorder + supernodes (host, once)
 //   CholeskyOf_FBS (up-looking, serial)     src/slam/BlockMatrixFBS.inl:2342     -> multifrontal fronts, level-parallel
-//   UpperTriangularTranspose_Solve_FBS      src/slam/BlockMatrixFBS.inl:2136     -> fwd_kernel (leaves -> root)
+//   UpperTriangularTranspose_Solve_FBS      src/slam/BlockMatrixFBS.inl:2136     -> inside the factorization (slot column)
 //   UpperTriangular_Solve_FBS               src/slam/BlockMatrixFBS.inl:2233     -> bwd_kernel (root -> leaves)
 //   (Inverse)Permute_LeftHandSide_Vector    src/slam/BlockMatrix.cpp:9323,9379   -> gather/scatter by scalar permutation
 //
@@ -407,7 +407,13 @@ void sparse_analyze(spp_ctx *ctx, const Structure &st)
 				w = h;
 		}
 		loc_off[s][sn_rows[s].size()] = h;
-		SPP_REQUIRE(h < 32768, SPP_E_UNSUPPORTED, "front too large for 16-bit local indices");
+		SPP_REQUIRE(h < 32767, SPP_E_UNSUPPORTED, "front too large for 16-bit local indices");
+		// The right-hand side rides along as ONE EXTRA non-pivot row / column of every front (local index h_real):
+		// its column holds b on the pivot rows, the factorization's row-panel and update steps turn that into y and
+		// into the residual handed to the parent (the extend-add maps the child's slot onto the parent's), so the
+		// forward substitution R^T y = b costs no launch of its own -- as in the dense factor (padding column n).
+		const int32_t h_real = h;
+		h = h_real + 1;
 		front_h[s] = h;
 		front_w[s] = w;
 		// size class: the in-LDS kernels pad the pivot block to a multiple of 16 inside their image
@@ -429,10 +435,11 @@ void sparse_analyze(spp_ctx *ctx, const Structure &st)
 		for(size_t q = 0; q < sn_rows[s].size(); ++ q)
 			for(int32_t e = 0; e < pdim[sn_rows[s][q]]; ++ e)
 				rows.push_back((int32_t)(pbase[sn_rows[s][q]] + e));
-		// flops of the partial factorization: sum over pivots of (remaining width)^2
+		rows.push_back(0); // the right-hand-side slot has no global row (never dereferenced)
+		// flops of the partial factorization: sum over pivots of (remaining width)^2 (the matrix alone)
 		for(int32_t j = 0; j < w; ++ j)
-			flops += (double)(h - j) * (double)(h - j);
-		nnz_r += (int64_t)w * h - (int64_t)w * (w - 1) / 2;
+			flops += (double)(h_real - j) * (double)(h_real - j);
+		nnz_r += (int64_t)w * h_real - (int64_t)w * (w - 1) / 2;
 	}
 	// regroup the level lists by size class
 	sp->h_cls_ptr.assign(sp->n_levels * NCLS + 1, 0);
@@ -495,6 +502,7 @@ void sparse_analyze(spp_ctx *ctx, const Structure &st)
 			for(int32_t e = 0; e < pdim[g]; ++ e)
 				rel.push_back(loc_off[p][qp] + e);
 		}
+		rel.push_back(loc_off[p][pr.size()]); // the child's right-hand-side slot -> the parent's
 		rel_ptr[s + 1] = (int32_t)rel.size();
 	}
 
@@ -608,6 +616,7 @@ void front_lds_kernel(const int32_t *__restrict__ list, const int64_t *__restric
 	const int32_t *__restrict__ front_pad, const int32_t *__restrict__ asm_ptr, const int64_t *__restrict__ asm_src,
 	const int32_t *__restrict__ asm_dst, const int32_t *__restrict__ asm_shape, const int32_t *__restrict__ child_ptr,
 	const int32_t *__restrict__ child_list, const int32_t *__restrict__ rel_ptr, const int32_t *__restrict__ rel,
+	const int32_t *__restrict__ rows_ptr, const int32_t *__restrict__ rows, const double *__restrict__ xperm,
 	const double *__restrict__ vals, double *__restrict__ fronts, int *__restrict__ info)
 {
 	// GMEM: the image is the front's own HBM buffer (already in the 16-padded layout, stride ld);
@@ -653,8 +662,15 @@ void front_lds_kernel(const int32_t *__restrict__ list, const int64_t *__restric
 			T[(dr + r) + (dc + c) * TSF] = (so & 1) ? src[c + ncol * r] : src[r + nr * c];
 		}
 	}
+	// ---- the right-hand side on the pivot rows: column h - 1 (the slot every front carries, see sparse_analyze)
+	{
+		const int32_t *rw = rows + rows_ptr[s];
+		const int cs = padded(h - 1, w, pad);
+		for(int r = tid; r < w; r += NTH)
+			T[r + (int64_t)cs * TSF] = xperm[rw[r]];
+	}
 	__syncthreads();
-	// ---- extend-add of the children's update matrices, children in list order
+	// ---- extend-add of the children's update matrices (their right-hand-side column included), children in list order
 	for(int cq = child_ptr[s]; cq < child_ptr[s + 1]; ++ cq) {
 		const int c = child_list[cq];
 		const int hc = front_h[c], wc = front_w[c], ldc = front_ld[c], oc = wc + front_pad[c];
@@ -803,14 +819,20 @@ __global__ __launch_bounds__(256)
 void bigfront_scatter_kernel(int s, const int64_t *__restrict__ front_off, const int32_t *__restrict__ front_w,
 	const int32_t *__restrict__ front_ld, const int32_t *__restrict__ front_pad, const int32_t *__restrict__ asm_ptr,
 	const int64_t *__restrict__ asm_src, const int32_t *__restrict__ asm_dst, const int32_t *__restrict__ asm_shape,
-	const double *__restrict__ vals, double *__restrict__ fronts)
+	const double *__restrict__ vals, double *__restrict__ fronts, const int32_t *__restrict__ front_h,
+	const int32_t *__restrict__ rows_ptr, const int32_t *__restrict__ rows, const double *__restrict__ xperm)
 {
 	const int w = front_w[s], ld = front_ld[s], pad = front_pad[s];
 	double *F = fronts + front_off[s];
 	const int tid = threadIdx.x, lane = tid & 63;
-	if(blockIdx.x == 0) // identity padding of the pivot block
+	if(blockIdx.x == 0) { // identity padding of the pivot block, right-hand side on the pivot rows (slot column h - 1)
 		for(int i = w + tid; i < w + pad; i += 256)
 			F[i + (int64_t)i * ld] = 1.0;
+		const int32_t *rw = rows + rows_ptr[s];
+		const int cs = padded(front_h[s] - 1, w, pad);
+		for(int r = tid; r < w; r += 256)
+			F[r + (int64_t)cs * ld] = xperm[rw[r]];
+	}
 	const int q = asm_ptr[s] + blockIdx.x * 4 + (tid >> 6);
 	if(q >= asm_ptr[s + 1])
 		return;
@@ -843,90 +865,13 @@ void bigfront_extend_kernel(int s, int c, const int64_t *__restrict__ front_off,
 		F[padded(rl[i], w, pad) + (int64_t)padded(rl[j], w, pad) * ld] += Fc[(oc + i) + (int64_t)(oc + j) * ldc];
 }
 
-// ---- multifrontal triangular solves, blocked by 64 pivots, column-oriented (coalesced) -------------
-// forward  R^T y = b (leaves -> root):  per block  y_B = R_BB^-T v_B  (64-step substitution by one wave
-//          on an LDS copy of the 64 x 64 triangle), then  v_c -= R[B, c]^T y_B  for every later column c
-//          (each thread streams the 64 contiguous entries of its column).
-// backward R x = y (root -> leaves):    per block  t_B = v_B - sum_{c after B} R[B, c] x_c  (lane = row of
+// ---- multifrontal triangular solves ------------------------------------------------------------------
+// forward  R^T y = b (leaves -> root):  no kernel of its own -- b rides through the factorization as the slot column
+//          of every front (sparse_analyze), which leaves y on the pivot rows of that column.
+// backward R x = y (root -> leaves), blocked by 64 pivots:    per block  t_B = v_B - sum_{c after B} R[B, c] x_c  (lane = row of
 //          the block: every column contributes 64 contiguous doubles), then x_B = R_BB^-1 t_B.
 // v = work vector of the front (length h, unpadded local indices) in HBM.
 constexpr int SB = 64;
-
-__global__ __launch_bounds__(FT)
-void front_fwd_kernel(const int32_t *__restrict__ level_fronts, const int64_t *__restrict__ front_off,
-	const int32_t *__restrict__ front_h, const int32_t *__restrict__ front_w, const int32_t *__restrict__ front_ld,
-	const int32_t *__restrict__ front_pad,
-	const int64_t *__restrict__ front_voff, const int32_t *__restrict__ child_ptr, const int32_t *__restrict__ child_list,
-	const int32_t *__restrict__ rel_ptr, const int32_t *__restrict__ rel, const int32_t *__restrict__ rows_ptr,
-	const int32_t *__restrict__ rows, const double *__restrict__ fronts, double *__restrict__ vbuf,
-	double *__restrict__ xperm)
-{
-	__shared__ double tri[SB * (SB + 1)];
-	__shared__ double yb[SB];
-	const int s = level_fronts[blockIdx.x];
-	const int h = front_h[s], w = front_w[s], ld = front_ld[s], pad = front_pad[s];
-	const double *F = fronts + front_off[s];
-	double *v = vbuf + front_voff[s];
-	const int32_t *rw = rows + rows_ptr[s];
-	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	for(int c = tid; c < h; c += FT)
-		v[c] = (c < w) ? xperm[rw[c]] : 0.0;
-	__syncthreads();
-	for(int cq = child_ptr[s]; cq < child_ptr[s + 1]; ++ cq) {
-		const int c = child_list[cq];
-		const int hc = front_h[c], wc = front_w[c];
-		const double *vc = vbuf + front_voff[c];
-		const int32_t *rl = rel + rel_ptr[c];
-		for(int i = tid; i < hc - wc; i += FT)
-			v[rl[i]] += vc[wc + i];
-		__syncthreads();
-	}
-	for(int j0 = 0; j0 < w; j0 += SB) {
-		const int nbk = (w - j0 < SB) ? (w - j0) : SB;
-		for(int e = tid; e < nbk * nbk; e += FT) {
-			const int i = e % nbk, k = e / nbk;
-			if(i <= k)
-				tri[i + k * (SB + 1)] = F[(j0 + i) + (int64_t)(j0 + k) * ld];
-		}
-		__syncthreads();
-		if(wave == 0) {
-			// 64-step substitution by one wave: the reciprocals of the diagonal are taken once (one division
-			// per lane instead of one per step), and the running value travels through v_readlane with a
-			// compile-time lane (full unroll) instead of a ds_bpermute per step
-			double b = (lane < nbk) ? v[j0 + lane] : 0.0;
-			const double rinv = (lane < nbk) ? 1.0 / tri[lane + lane * (SB + 1)] : 0.0;
-#pragma unroll
-			for(int i = 0; i < SB; ++ i) {
-				if(i < nbk) { // wave-uniform
-					const double yi = readlane_f64(b, i) * readlane_f64(rinv, i);
-					const double tcol = tri[i + lane * (SB + 1)];
-					b = (lane == i) ? yi : ((lane > i && lane < nbk) ? b - tcol * yi : b);
-				}
-			}
-			if(lane < nbk) {
-				yb[lane] = b;
-				v[j0 + lane] = b;
-			}
-		}
-		__syncthreads();
-		for(int c = j0 + nbk + tid; c < h; c += FT) {
-			const double *col = F + j0 + (int64_t)padded(c, w, pad) * ld;
-			double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-			int i = 0;
-			for(; i + 8 <= nbk; i += 8) {
-#pragma unroll
-				for(int u = 0; u < 8; ++ u)
-					acc[u] += col[i + u] * yb[i + u];
-			}
-			for(; i < nbk; ++ i)
-				acc[0] += col[i] * yb[i];
-			v[c] -= ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
-		}
-		__syncthreads();
-	}
-	for(int c = tid; c < w; c += FT)
-		xperm[rw[c]] = v[c];
-}
 
 __global__ __launch_bounds__(FT)
 void front_bwd_kernel(const int32_t *__restrict__ level_fronts, const int64_t *__restrict__ front_off,
@@ -943,8 +888,13 @@ void front_bwd_kernel(const int32_t *__restrict__ level_fronts, const int64_t *_
 	double *v = vbuf + front_voff[s];
 	const int32_t *rw = rows + rows_ptr[s];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	for(int c = tid; c < h; c += FT)
-		v[c] = xperm[rw[c]]; // own part: y ; beyond: final x of the ancestors
+	// own part: y = the slot column of the factored front (the forward substitution happened inside the factorization);
+	// beyond: final x of the ancestors; the slot itself takes no part (0)
+	{
+		const int cs = padded(h - 1, w, pad);
+		for(int c = tid; c < h; c += FT)
+			v[c] = (c < w) ? F[c + (int64_t)cs * ld] : ((c < h - 1) ? xperm[rw[c]] : 0.0);
+	}
 	__syncthreads();
 	const int nblk = (w + SB - 1) / SB;
 	for(int bk = nblk; bk > 0;) {
@@ -983,7 +933,7 @@ void front_bwd_kernel(const int32_t *__restrict__ level_fronts, const int64_t *_
 			}
 			const double rinv = (lane < nbk) ? 1.0 / tri[lane + lane * (SB + 1)] : 0.0;
 #pragma unroll
-			for(int i = SB; i > 0;) { // as in the forward kernel: reciprocals once, v_readlane with compile-time lanes
+			for(int i = SB; i > 0;) { // reciprocals of the diagonal once, the running value through v_readlane with compile-time lanes
 				-- i;
 				if(i < nbk) { // wave-uniform
 					const double xi = readlane_f64(t, i) * readlane_f64(rinv, i);
@@ -1031,7 +981,7 @@ static void launch_front_lds(spp_ctx *ctx, SparsePlan *sp, int32_t b, int32_t e,
 	hipLaunchKernelGGL((front_lds_kernel<HP, NTH, GMEM>), dim3((unsigned)(e - b)), dim3(NTH), lds, ctx->stream,
 		sp->level_fronts.p + b, sp->front_off.p, sp->front_h.p, sp->front_w.p, sp->front_ld.p, sp->front_pad.p,
 		sp->asm_ptr.p, sp->asm_src.p, sp->asm_dst.p, sp->asm_shape.p, sp->child_ptr.p, sp->child_list.p,
-		sp->rel_ptr.p, sp->rel.p, d_vals, sp->fronts.p, ctx->dense.info.p);
+		sp->rel_ptr.p, sp->rel.p, sp->rows_ptr.p, sp->rows.p, sp->xperm.p, d_vals, sp->fronts.p, ctx->dense.info.p);
 }
 
 static void sparse_enqueue(spp_ctx *ctx, const double *d_vals, double *d_rhs);
@@ -1094,6 +1044,8 @@ static void sparse_enqueue(spp_ctx *ctx, const double *d_vals, double *d_rhs)
 	const unsigned gn = (unsigned)((sp->n + 255) / 256);
 	dense_info_reset(ctx);
 	phase_begin(ctx, SPP_PHASE_FACTOR);
+	// P b: every front takes its pivot rows of it as its right-hand-side column
+	hipLaunchKernelGGL(gather_perm_kernel, dim3(gn), dim3(256), 0, s, sp->n, sp->perm_scalar.p, d_rhs, sp->xperm.p);
 	for(int64_t l = 0; l < sp->n_levels; ++ l) {
 		const int32_t *cp = sp->h_cls_ptr.data() + l * NCLS;
 		launch_front_lds<32, 64, false>(ctx, sp, cp[0], cp[1], d_vals);
@@ -1109,7 +1061,7 @@ static void sparse_enqueue(spp_ctx *ctx, const double *d_vals, double *d_rhs)
 			const int32_t nasm = sp->h_asm_ptr[f + 1] - sp->h_asm_ptr[f];
 			hipLaunchKernelGGL(bigfront_scatter_kernel, dim3((unsigned)((nasm + 3) / 4 + 1)), dim3(256), 0, s,
 				f, sp->front_off.p, sp->front_w.p, sp->front_ld.p, sp->front_pad.p, sp->asm_ptr.p, sp->asm_src.p,
-				sp->asm_dst.p, sp->asm_shape.p, d_vals, sp->fronts.p);
+				sp->asm_dst.p, sp->asm_shape.p, d_vals, sp->fronts.p, sp->front_h.p, sp->rows_ptr.p, sp->rows.p, sp->xperm.p);
 			for(int32_t cq = sp->h_child_ptr[f]; cq < sp->h_child_ptr[f + 1]; ++ cq) {
 				const int32_t c = sp->h_child_list[cq];
 				const int64_t m = sp->h_front_h[c] - sp->h_front_w[c];
@@ -1124,14 +1076,7 @@ static void sparse_enqueue(spp_ctx *ctx, const double *d_vals, double *d_rhs)
 	phase_end(ctx, SPP_PHASE_FACTOR);
 	SPP_HIP_CHECK(hipGetLastError());
 	phase_begin(ctx, SPP_PHASE_TRISOLVE);
-	hipLaunchKernelGGL(gather_perm_kernel, dim3(gn), dim3(256), 0, s, sp->n, sp->perm_scalar.p, d_rhs, sp->xperm.p);
-	for(int64_t l = 0; l < sp->n_levels; ++ l) {
-		const int32_t b = sp->h_level_ptr[l], e = sp->h_level_ptr[l + 1];
-		hipLaunchKernelGGL(front_fwd_kernel, dim3((unsigned)(e - b)), dim3(FT), 0, s,
-			sp->level_fronts.p + b, sp->front_off.p, sp->front_h.p, sp->front_w.p, sp->front_ld.p, sp->front_pad.p,
-			sp->front_voff.p, sp->child_ptr.p, sp->child_list.p, sp->rel_ptr.p, sp->rel.p, sp->rows_ptr.p, sp->rows.p,
-			sp->fronts.p, sp->vbuf.p, sp->xperm.p);
-	}
+	// the forward substitution R^T y = P b was carried by the factorization (slot column of every front): backward only
 	for(int64_t l = sp->n_levels; l > 0;) {
 		-- l;
 		const int32_t b = sp->h_level_ptr[l], e = sp->h_level_ptr[l + 1];
