@@ -672,6 +672,21 @@ __device__ __forceinline__ void potrf_diag_body(double *__restrict__ Ablk, int64
 			return;
 		SPP_STAMP(3 + 6 * J, 0);
 		const int j0 = J * 16;
+		if(j0 >= n_valid) {
+			// a panel of padding only (exact identity rows / columns, nothing right of them in these rows): its rows of R and
+			// its columns of the inverse are unit vectors; nothing to eliminate, no LDS traffic, no barrier (uniform branch)
+			const int nv16 = (n_valid + 15) & ~15;
+			for(int e = tid; e < 16 * (NB - j0); e += POTRF_THREADS) {
+				const int r = j0 + (e & 15), c = j0 + (e >> 4);
+				if(r <= c && c != rhs_col)
+					Ablk[r + (int64_t)c * ld] = (r == c) ? 1.0 : 0.0;
+			}
+			for(int e = tid; e < 16 * NB; e += POTRF_THREADS) {
+				const int r = e & (NB - 1), c = j0 + (e >> 7);
+				tinv[r + c * NB] = (r == c) ? 1.0 : ((r < c && r < nv16) ? T[c + r * TS] : 0.0); // G[c][r] of the valid rows: zeros, assigned there
+			}
+			continue;
+		}
 		const double *Dv = DvB + (J & 1) * 16 * PT, *Gd = GdB + (J & 1) * 16 * PT;
 		// ---- B: row panel. tiles t < J: G part (columns 16 t ..), tiles t >= J: R part (columns 16 (t + 1) ..)
 		if(wave < 7) {
@@ -718,7 +733,7 @@ __device__ __forceinline__ void potrf_diag_body(double *__restrict__ Ablk, int64
 				}
 			};
 			if(wave == 0) {
-				if(nI > 0) {
+				if(nI > 0 && j0 + 16 < n_valid) { // (a next tile of padding only is not factored: its panel is skipped)
 					const double *Pa = T + j0 + ((J + 1) * 16) * TS;
 					const v4f64 d = tile_atb(Pa, 1, TS, Pa, 1, TS, lane);
 					double *D = T + ((J + 1) * 16) + ((J + 1) * 16) * TS;
@@ -1280,6 +1295,9 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 	// flag[2 k + 1] = "bulk update k is complete" (signal kernel behind it on s2; the tile-row kernel of the
 	// chain polls it in its own prologue). Values are the epoch of this factorization.
 	DenseWork &dw = ctx->dense;
+	// pivots [n_id, n) are exact identity padding (big fronts of the sparse path pad their pivot block to a multiple of
+	// 128): the diagonal-block kernel skips the 16-wide panels that consist of padding only
+	const int64_t n_id = (dw.ident_from >= 0 && dw.ident_from < n) ? dw.ident_from : n;
 	int ep = 0;
 	int64_t step_a = -1, step_b = -1; // steps whose hand-over / bulk update the "events" currently name
 	int64_t need_wait_b = -1;         // flags only: the next chain kernel has to wait for bulk update need_wait_b
@@ -1396,7 +1414,7 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 		const int64_t nbi = (m + 63) / 64, nbj = (N + 63) / 64;
 		const int do_potrf = kn >= 0 ? 1 : 0;
 		const int64_t kn0 = (kn >= 0 ? kn : 0) * NB;
-		const int n_valid = (int)((n - kn0 < NB) ? (n - kn0) : NB);
+		const int n_valid = (int)std::max<int64_t>(0, std::min<int64_t>(NB, n_id - kn0));
 		hipLaunchKernelGGL(update_potrf_kernel, dim3((unsigned)(nA + do_potrf + nbi * nbj)), dim3(POTRF_THREADS),
 			POTRF_LDS_DOUBLES * sizeof(double), s, m, N, d_A + kp0 + r0 * ld, ld, d_A + r0 + r0 * ld, nA, do_potrf,
 			n_valid, (has_rhs && n_valid < NB) ? 1 : 0, dw.tinv_all.p + (size_t)(kn >= 0 ? kn : 0) * NB * NB, dw.info.p, kn0,
@@ -1405,7 +1423,7 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 	};
 	auto potrf_and_panel = [&](hipStream_t st, int64_t k, bool potrf_done = false) {
 		const int64_t k0 = k * NB;
-		const int n_valid = (int)((n - k0 < NB) ? (n - k0) : NB);
+		const int n_valid = (int)std::max<int64_t>(0, std::min<int64_t>(NB, n_id - k0));
 		double *tinv = ctx->dense.tinv_all.p + (size_t)k * NB * NB;
 		if(!potrf_done)
 		hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(POTRF_THREADS), POTRF_LDS_DOUBLES * sizeof(double), st,

@@ -814,55 +814,90 @@ void front_lds_kernel(const int32_t *__restrict__ list, const int64_t *__restric
 }
 
 // ---- big fronts (image does not fit LDS): assembled in HBM in the padded layout, factored by the
-// multi-workgroup dense kernels (spp_dense.hip)
-__global__ __launch_bounds__(256)
-void bigfront_scatter_kernel(int s, const int64_t *__restrict__ front_off, const int32_t *__restrict__ front_w,
-	const int32_t *__restrict__ front_ld, const int32_t *__restrict__ front_pad, const int32_t *__restrict__ asm_ptr,
-	const int64_t *__restrict__ asm_src, const int32_t *__restrict__ asm_dst, const int32_t *__restrict__ asm_shape,
-	const double *__restrict__ vals, double *__restrict__ fronts, const int32_t *__restrict__ front_h,
-	const int32_t *__restrict__ rows_ptr, const int32_t *__restrict__ rows, const double *__restrict__ xperm)
-{
-	const int w = front_w[s], ld = front_ld[s], pad = front_pad[s];
-	double *F = fronts + front_off[s];
-	const int tid = threadIdx.x, lane = tid & 63;
-	if(blockIdx.x == 0) { // identity padding of the pivot block, right-hand side on the pivot rows (slot column h - 1)
-		for(int i = w + tid; i < w + pad; i += 256)
-			F[i + (int64_t)i * ld] = 1.0;
-		const int32_t *rw = rows + rows_ptr[s];
-		const int cs = padded(front_h[s] - 1, w, pad);
-		for(int r = tid; r < w; r += 256)
-			F[r + (int64_t)cs * ld] = xperm[rw[r]];
-	}
-	const int q = asm_ptr[s] + blockIdx.x * 4 + (tid >> 6);
-	if(q >= asm_ptr[s + 1])
-		return;
-	const int64_t so = asm_src[q];
-	const double *src = vals + (so >> 1);
-	const int dr = padded(asm_dst[q] & 0xffff, w, pad), dc = padded(asm_dst[q] >> 16, w, pad);
-	const int nr = asm_shape[q] & 0xff, ncol = asm_shape[q] >> 8;
-	if(lane < nr * ncol) {
-		const int r = lane % nr, c = lane / nr;
-		F[(dr + r) + (int64_t)(dc + c) * ld] = (so & 1) ? src[c + ncol * r] : src[r + nr * c];
-	}
-}
+// multi-workgroup dense kernels (spp_dense.hip). ONE launch assembles a front: a workgroup owns BFC columns of the
+// padded front and, for them, clears the column, sets the identity padding of the pivot block, takes the pivot rows of
+// the right-hand side (slot column), the blocks of Lambda, and then the update matrices of the children IN LIST ORDER
+// (column ownership: no races, the same summation order run to run). It used to be a memset, a scatter kernel and one
+// extend-add kernel per child -- five launches of ~5 us each in front of a 28 us factorization.
+constexpr int BFC = 8;
 
 __global__ __launch_bounds__(256)
-void bigfront_extend_kernel(int s, int c, const int64_t *__restrict__ front_off, const int32_t *__restrict__ front_h,
+void bigfront_assemble_kernel(int s, const int64_t *__restrict__ front_off, const int32_t *__restrict__ front_h,
 	const int32_t *__restrict__ front_w, const int32_t *__restrict__ front_ld, const int32_t *__restrict__ front_pad,
-	const int32_t *__restrict__ rel_ptr, const int32_t *__restrict__ rel, double *__restrict__ fronts)
+	const int32_t *__restrict__ asm_ptr, const int64_t *__restrict__ asm_src, const int32_t *__restrict__ asm_dst,
+	const int32_t *__restrict__ asm_shape, const int32_t *__restrict__ child_ptr, const int32_t *__restrict__ child_list,
+	const int32_t *__restrict__ rel_ptr, const int32_t *__restrict__ rel, const int32_t *__restrict__ rows_ptr,
+	const int32_t *__restrict__ rows, const double *__restrict__ xperm, const double *__restrict__ vals,
+	double *__restrict__ fronts)
 {
-	const int w = front_w[s], ld = front_ld[s], pad = front_pad[s];
+	__shared__ int jrange[2];
+	const int h = front_h[s], w = front_w[s], ld = front_ld[s], pad = front_pad[s];
+	const int hp = h + pad;
 	double *F = fronts + front_off[s];
-	const int hc = front_h[c], wc = front_w[c], ldc = front_ld[c], oc = wc + front_pad[c];
-	const double *Fc = fronts + front_off[c];
-	const int32_t *rl = rel + rel_ptr[c];
-	const int m = hc - wc;
-	const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-	if(e >= (int64_t)m * m)
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int c0 = (int)blockIdx.x * BFC, c1 = (c0 + BFC < hp) ? c0 + BFC : hp; // padded columns of this workgroup
+	if(c0 >= hp)
 		return;
-	const int i = (int)(e % m), j = (int)(e / m);
-	if(i <= j)
-		F[padded(rl[i], w, pad) + (int64_t)padded(rl[j], w, pad) * ld] += Fc[(oc + i) + (int64_t)(oc + j) * ldc];
+	for(int e = tid; e < (c1 - c0) * ld; e += 256)
+		F[(int64_t)c0 * ld + e] = 0.0;
+	__syncthreads();
+	for(int i = c0 + tid; i < c1; i += 256)
+		if(i >= w && i < w + pad)
+			F[i + (int64_t)i * ld] = 1.0; // identity padding of the pivot block
+	{
+		const int cs = padded(h - 1, w, pad); // the right-hand-side slot
+		if(cs >= c0 && cs < c1) {
+			const int32_t *rw = rows + rows_ptr[s];
+			for(int r = tid; r < w; r += 256)
+				F[r + (int64_t)cs * ld] = xperm[rw[r]];
+		}
+	}
+	// ---- blocks of Lambda: every workgroup walks the front's list and keeps the elements of its columns
+	for(int q = asm_ptr[s] + wave; q < asm_ptr[s + 1]; q += 4) {
+		const int64_t so = asm_src[q];
+		const double *src = vals + (so >> 1);
+		const int dr = padded(asm_dst[q] & 0xffff, w, pad), dc = padded(asm_dst[q] >> 16, w, pad);
+		const int nr = asm_shape[q] & 0xff, ncol = asm_shape[q] >> 8;
+		if(dc + ncol <= c0 || dc >= c1)
+			continue; // wave-uniform
+		if(lane < nr * ncol) {
+			const int r = lane % nr, c = lane / nr;
+			if(dc + c >= c0 && dc + c < c1)
+				F[(dr + r) + (int64_t)(dc + c) * ld] = (so & 1) ? src[c + ncol * r] : src[r + nr * c];
+		}
+	}
+	__syncthreads();
+	// ---- extend-add, children in list order; a child's rows map to ascending parent indices, so the child columns
+	// that land in [c0, c1) are one contiguous range [ja, jb)
+	for(int cq = child_ptr[s]; cq < child_ptr[s + 1]; ++ cq) {
+		const int c = child_list[cq];
+		const int hc = front_h[c], wc = front_w[c], ldc = front_ld[c], oc = wc + front_pad[c];
+		const double *Fc = fronts + front_off[c];
+		const int32_t *rl = rel + rel_ptr[c];
+		const int m = hc - wc;
+		if(tid == 0) {
+			int lo = 0, hi = m; // first j with padded(rl[j]) >= c0
+			while(lo < hi) {
+				const int mid = (lo + hi) >> 1;
+				if(padded(rl[mid], w, pad) < c0) lo = mid + 1; else hi = mid;
+			}
+			jrange[0] = lo;
+			hi = m; // first j with padded(rl[j]) >= c1
+			while(lo < hi) {
+				const int mid = (lo + hi) >> 1;
+				if(padded(rl[mid], w, pad) < c1) lo = mid + 1; else hi = mid;
+			}
+			jrange[1] = lo;
+		}
+		__syncthreads();
+		const int ja = jrange[0], jb = jrange[1];
+		for(int e = tid; e < (jb - ja) * m; e += 256) {
+			const int j = ja + e / m, i = e % m;
+			if(i <= j)
+				F[padded(rl[i], w, pad) + (int64_t)padded(rl[j], w, pad) * ld] += Fc[(oc + i) + (int64_t)(oc + j) * ldc];
+		}
+		__syncthreads();
+	}
 }
 
 // ---- multifrontal triangular solves ------------------------------------------------------------------
@@ -1057,19 +1092,15 @@ static void sparse_enqueue(spp_ctx *ctx, const double *d_vals, double *d_rhs)
 			const int32_t h = sp->h_front_h[f], w = sp->h_front_w[f], pad = sp->h_front_pad[f], ld = sp->h_front_ld[f];
 			const int32_t hp = h + pad;
 			double *F = sp->fronts.p + sp->h_front_off[f];
-			SPP_HIP_CHECK(hipMemsetAsync(F, 0, (size_t)ld * hp * sizeof(double), s));
-			const int32_t nasm = sp->h_asm_ptr[f + 1] - sp->h_asm_ptr[f];
-			hipLaunchKernelGGL(bigfront_scatter_kernel, dim3((unsigned)((nasm + 3) / 4 + 1)), dim3(256), 0, s,
-				f, sp->front_off.p, sp->front_w.p, sp->front_ld.p, sp->front_pad.p, sp->asm_ptr.p, sp->asm_src.p,
-				sp->asm_dst.p, sp->asm_shape.p, d_vals, sp->fronts.p, sp->front_h.p, sp->rows_ptr.p, sp->rows.p, sp->xperm.p);
-			for(int32_t cq = sp->h_child_ptr[f]; cq < sp->h_child_ptr[f + 1]; ++ cq) {
-				const int32_t c = sp->h_child_list[cq];
-				const int64_t m = sp->h_front_h[c] - sp->h_front_w[c];
-				if(m > 0)
-					hipLaunchKernelGGL(bigfront_extend_kernel, dim3((unsigned)((m * m + 255) / 256)), dim3(256), 0, s,
-						f, c, sp->front_off.p, sp->front_h.p, sp->front_w.p, sp->front_ld.p, sp->front_pad.p,
-						sp->rel_ptr.p, sp->rel.p, sp->fronts.p);
-			}
+			hipLaunchKernelGGL(bigfront_assemble_kernel, dim3((unsigned)((hp + BFC - 1) / BFC)), dim3(256), 0, s,
+				f, sp->front_off.p, sp->front_h.p, sp->front_w.p, sp->front_ld.p, sp->front_pad.p, sp->asm_ptr.p, sp->asm_src.p,
+				sp->asm_dst.p, sp->asm_shape.p, sp->child_ptr.p, sp->child_list.p, sp->rel_ptr.p, sp->rel.p, sp->rows_ptr.p,
+				sp->rows.p, sp->xperm.p, d_vals, sp->fronts.p);
+			struct IdentGuard { // pivots [w, w + pad) are identity padding: the diagonal-block kernel skips their panels
+				DenseWork &d;
+				IdentGuard(DenseWork &dw, int64_t from) : d(dw) { d.ident_from = from; }
+				~IdentGuard() { d.ident_from = -1; }
+			} guard(ctx->dense, w);
 			dense_factor_steps(ctx, F, ld, w + pad, hp, hp, (w + pad) / DENSE_NB, false);
 		}
 	}
