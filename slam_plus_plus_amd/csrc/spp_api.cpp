@@ -135,6 +135,7 @@ int spp_free_memory(spp_ctx *ctx)
 	ctx->dense.epoch = 0;
 	ctx->dense.sync.release();
 	ctx->dense.fuse_cnt.release();
+	ctx->dense.fuse_expect.clear();
 	ctx->dense.sync_epoch = 0;
 	ctx->d_vals.release();
 	ctx->d_rhs.release();
@@ -268,7 +269,9 @@ int spp_analyze(spp_ctx *ctx, int64_t nb, const int64_t *col_ptr, const int64_t 
 	st.base.resize(nb + 1);
 	st.base[0] = 0;
 	for(int64_t j = 0; j < nb; ++ j) {
-		SPP_REQUIRE(dim[j] > 0 && dim[j] <= 6, SPP_E_BADARG, "block widths must be in 1..6");
+		// 7 = Sim(3) poses (include/slam/Sim3_Types.h); the sparse path works on scalar fronts and only needs a block to
+		// fit one wave in the assembly step (8 x 8 = 64 lanes); the Schur kernels are instantiated for {6,3}, {3,2}, 3, 6
+		SPP_REQUIRE(dim[j] > 0 && dim[j] <= 8, SPP_E_BADARG, "block widths must be in 1..8");
 		st.base[j + 1] = st.base[j] + dim[j];
 	}
 	st.n = st.base[nb];

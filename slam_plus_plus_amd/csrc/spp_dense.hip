@@ -857,7 +857,7 @@ void potrf_diag_kernel(double *__restrict__ Ablk, int64_t ld, int n_valid, int h
 // own launch (it needs the whole tile row AND the factor).
 // --------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(POTRF_THREADS)
-void update_potrf_kernel(int64_t M, int64_t N, const double *P, int64_t ld, double *C, int nA, int do_potrf,
+void update_potrf_kernel(int64_t M, int64_t N, const double *P, int64_t ld, double *C, int nA, int target, int do_potrf,
 	int n_valid, int has_rhs, double *tinv, int *info, int64_t k0_next, int *counter, int *abort, long long timeout_ticks)
 {
 	extern __shared__ double sm[];
@@ -889,7 +889,7 @@ void update_potrf_kernel(int64_t M, int64_t N, const double *P, int64_t ld, doub
 		if(tid == 0) {
 			const long long t0 = wall_clock64();
 			int ok = 1;
-			for(int it = 0; __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nA; ++ it) {
+			for(int it = 0; __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; ++ it) { // monotonic counter: its value after this launch's nA producers
 				if((it & 15) == 15) {
 					if(__hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
 						ok = 0;
@@ -1396,9 +1396,14 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 				POTRF_LDS_DOUBLES * (int)sizeof(double)));
 			fattr = true;
 		}
-		if(dw.fuse_cnt.cap < (size_t)(nsteps + 2))
-			dw.fuse_cnt.reserve((size_t)(nsteps + 2));
-		SPP_HIP_CHECK(hipMemsetAsync(dw.fuse_cnt.p, 0, (size_t)(nsteps + 2) * sizeof(int), s));
+		// per-step counters of finished diagonal sub-tiles: monotonic, never reset between factorizations (the host keeps
+		// the value each slot will have reached) -- a memset per call was a 4.5 us launch in front of every big front
+		if(dw.fuse_cnt.cap < (size_t)(nsteps + 2) || dw.fuse_dirty) {
+			dw.fuse_cnt.reserve(std::max<size_t>((size_t)(nsteps + 2), 64));
+			SPP_HIP_CHECK(hipMemsetAsync(dw.fuse_cnt.p, 0, dw.fuse_cnt.cap * sizeof(int), s));
+			dw.fuse_expect.assign(dw.fuse_cnt.cap, 0);
+			dw.fuse_dirty = false;
+		}
 	}
 	static_assert(POTRF_LDS_DOUBLES >= (64 + 64) * FS_STRIDE, "the fused kernel's LDS is sized by the factorization");
 	// region rows [r0, r0 + m) x cols [r0, ncols), panel rows at kp0; potrf of step kn when kn >= 0
@@ -1415,10 +1420,12 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 		const int do_potrf = kn >= 0 ? 1 : 0;
 		const int64_t kn0 = (kn >= 0 ? kn : 0) * NB;
 		const int n_valid = (int)std::max<int64_t>(0, std::min<int64_t>(NB, n_id - kn0));
+		const size_t slot = (size_t)(kn >= 0 ? kn : nsteps + 1);
+		dw.fuse_expect[slot] += nA;
 		hipLaunchKernelGGL(update_potrf_kernel, dim3((unsigned)(nA + do_potrf + nbi * nbj)), dim3(POTRF_THREADS),
-			POTRF_LDS_DOUBLES * sizeof(double), s, m, N, d_A + kp0 + r0 * ld, ld, d_A + r0 + r0 * ld, nA, do_potrf,
+			POTRF_LDS_DOUBLES * sizeof(double), s, m, N, d_A + kp0 + r0 * ld, ld, d_A + r0 + r0 * ld, nA, dw.fuse_expect[slot], do_potrf,
 			n_valid, (has_rhs && n_valid < NB) ? 1 : 0, dw.tinv_all.p + (size_t)(kn >= 0 ? kn : 0) * NB * NB, dw.info.p, kn0,
-			dw.fuse_cnt.p + (kn >= 0 ? kn : nsteps + 1), dw.info.p + 2, (long long)(500.0 * 1e5));
+			dw.fuse_cnt.p + slot, dw.info.p + 2, (long long)(500.0 * 1e5));
 		return true;
 	};
 	auto potrf_and_panel = [&](hipStream_t st, int64_t k, bool potrf_done = false) {
@@ -1674,6 +1681,7 @@ int dense_info_fetch(spp_ctx *ctx)
 	if(h_info[2]) { // a cross-stream flag wait timed out: the result is garbage, the flag hand-offs stay off
 		SPP_HIP_CHECK(hipMemset(ctx->dense.info.p + 2, 0, sizeof(int)));
 		ctx->dense.sync_state = -1;
+		ctx->dense.fuse_dirty = true; // the sub-tile counters of the aborted factorization are behind the host's bookkeeping
 		throw Error(SPP_E_HIP, "dense factorization: a cross-stream flag wait timed out (streams not concurrent?); "
 			"the following calls use the event schedule");
 	}

@@ -146,6 +146,8 @@ struct DenseWork {
 	// sync[2 k] = row panel k complete, sync[2 k + 1] = bulk update k complete, as the epoch of the factorization
 	DevBuf<int> sync;
 	DevBuf<int> fuse_cnt;          // per step: sub-tiles of the next diagonal tile finished (update_potrf_kernel)
+	std::vector<int> fuse_expect;  // host: the value every counter will have reached behind the launches enqueued so far
+	bool fuse_dirty = false;       // counters and bookkeeping disagree (aborted factorization): cleared before the next use
 	int64_t ident_from = -1;       // >= 0: the pivots from this index on are exact identity padding (set around a call by the sparse path)
 	int sync_epoch = 0;
 	int sync_state = 0;            // 0: not tested on this stream, 1: the streams run concurrently, -1: disabled

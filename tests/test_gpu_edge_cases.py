@@ -36,9 +36,12 @@ def _spd_blocks(dim, pairs, seed):
 
 
 @pytest.mark.parametrize("dim,pairs", [([3], []), ([6], []), ([3, 3], [(0, 1)]), ([2, 5, 1, 4, 6, 3], [(0, 1), (1, 2), (0, 5), (3, 4), (2, 4)]),
-                                       ([3] * 7, []), ([6, 3, 3], [(0, 1), (0, 2)])])
+                                       ([3] * 7, []), ([6, 3, 3], [(0, 1), (0, 2)]),
+                                       ([7] * 12, [(i, i + 1) for i in range(11)] + [(0, 6), (2, 9), (4, 11)]),
+                                       ([7, 3, 8, 7, 3, 3, 7], [(0, 1), (0, 3), (1, 3), (2, 3), (3, 4), (3, 6), (5, 6)])])
 def test_tiny_ragged_and_disconnected_systems(dim, pairs):
-    """one vertex, two vertices, block widths 1..6 mixed, only diagonal blocks (a disconnected graph), the smallest BA"""
+    """one vertex, two vertices, block widths 1..8 mixed (7 = Sim(3) poses, Sim3_Types.h), only diagonal blocks (a
+    disconnected graph), the smallest BA"""
     lam, L, eta = _spd_blocks(dim, pairs, 3)
     want = np.linalg.solve(L, eta)
     for mode in (api.MODE_AUTO, api.MODE_SPARSE):
@@ -87,7 +90,7 @@ def test_malformed_structures_are_rejected_not_executed(hip_ctx):
     bad = lam.row_idx.copy()
     bad[lam.col_ptr[1]] = 2                                            # a block below the diagonal
     assert analyze(lam.col_ptr, bad, lam.blk_off, lam.dim) < 0
-    assert analyze(lam.col_ptr, lam.row_idx, lam.blk_off, [3, 7, 3]) < 0   # block width outside 1..6
+    assert analyze(lam.col_ptr, lam.row_idx, lam.blk_off, [3, 9, 3]) < 0   # block width outside 1..8
     nodiag_cp, nodiag_ri = [0, 1, 2, 3], [0, 0, 1]                         # columns 1, 2 without their diagonal block
     assert analyze(nodiag_cp, nodiag_ri, [0, 9, 18], [3, 3, 3]) < 0
     neg = lam.blk_off.copy()
