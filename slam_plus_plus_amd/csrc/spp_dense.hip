@@ -350,7 +350,10 @@ __global__ void flag_signal_wait_kernel(int *flag, int value, FlagWait fw)
 
 // one BM x BN tile of C at (m0, n0) by the first (BM / WM) * (BN / WN) waves of the workgroup (the body shared by
 // gemm_tn_staged_kernel and the fused update + diagonal-block kernel); fs_lds: (BM + BN) * FS_STRIDE doubles
-template <int BM, int BN, int WM, int WN, int MODE, int ATRI>
+// SC1: the C tile is stored with agent-scope atomic (write-through) stores -- for a tile that another workgroup of the
+// SAME launch reads with agent-scope atomic loads after a counter hand-off (no release / acquire fences, see
+// update_potrf_kernel)
+template <int BM, int BN, int WM, int WN, int MODE, int ATRI, int SC1 = 0>
 __device__ __forceinline__ void gemm_tn_staged_tile(const int64_t m0, const int64_t n0, int64_t M, int64_t N,
 	const double *__restrict__ A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, double *fs_lds)
 {
@@ -435,8 +438,13 @@ __device__ __forceinline__ void gemm_tn_staged_tile(const int64_t m0, const int6
 #pragma unroll
 			for(int r = 0; r < 4; ++ r) {
 				const int64_t n = n0 + wn + b * 16 + l4 + 4 * r;
-				if(m < M && n < N)
-					C[m + n * ldc] = (MODE == 0) ? -acc[b][a][r] : acc[b][a][r];
+				if(m < M && n < N) {
+					const double val = (MODE == 0) ? -acc[b][a][r] : acc[b][a][r];
+					if(SC1)
+						__hip_atomic_store(&C[m + n * ldc], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					else
+						C[m + n * ldc] = val;
+				}
 			}
 		}
 }
@@ -571,6 +579,21 @@ __device__ __forceinline__ void lds_barrier()
 	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// COH: the block was written by other workgroups of the same launch with write-through stores: read it with
+// agent-scope atomic (sc1) loads -- they bypass this CU's L1, which a plain load could be served from stale
+template <bool COH>
+__device__ __forceinline__ double2 ld_blk2(const double *p)
+{
+	if(COH) {
+		double2 v;
+		v.x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		v.y = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		return v;
+	}
+	return *(const double2*)p;
+}
+
+template <bool COH = false>
 __device__ __forceinline__ void potrf_diag_body(double *__restrict__ Ablk, int64_t ld, int n_valid, int has_rhs,
 	double *__restrict__ tinv, int *__restrict__ info, int64_t k0, double *sm)
 {
@@ -596,7 +619,8 @@ __device__ __forceinline__ void potrf_diag_body(double *__restrict__ Ablk, int64
 			double v[4];
 #pragma unroll
 			for(int t = 0; t < 4; ++ t)
-				v[t] = Ablk[l15 + (int64_t)(l4 + 4 * t) * ld];
+				v[t] = COH ? __hip_atomic_load(&Ablk[l15 + (int64_t)(l4 + 4 * t) * ld], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+				           : Ablk[l15 + (int64_t)(l4 + 4 * t) * ld];
 #pragma unroll
 			for(int t = 0; t < 4; ++ t)
 				T[l15 + (l4 + 4 * t) * TS] = v[t];
@@ -614,7 +638,7 @@ __device__ __forceinline__ void potrf_diag_body(double *__restrict__ Ablk, int64
 				// only the upper triangle is an input (16 x 16 tiles on or above the diagonal): the tiles below it
 				// are first ASSIGNED by the G part of the update, never read before -- 44 % of the block not fetched
 				if(e < NP && !(r < 16 && c < 16) && (r >> 4) <= (c >> 4))
-					v[t] = *(const double2*)(Ablk + r + (int64_t)c * ld);
+					v[t] = ld_blk2<COH>(Ablk + r + (int64_t)c * ld);
 			}
 #pragma unroll
 			for(int t = 0; t < NIT; ++ t) {
@@ -642,7 +666,7 @@ __device__ __forceinline__ void potrf_diag_body(double *__restrict__ Ablk, int64
 #pragma unroll
 			for(int t = 0; t < NB * NB / 2 / POTRF_THREADS; ++ t) {
 				const int e = tid + t * POTRF_THREADS, r = (e & (NB / 2 - 1)) * 2, c = e >> 6;
-				v[t] = *(const double2*)(Ablk + r + (int64_t)c * ld);
+				v[t] = ld_blk2<COH>(Ablk + r + (int64_t)c * ld);
 			}
 #pragma unroll
 			for(int t = 0; t < NB * NB / 2 / POTRF_THREADS; ++ t) {
@@ -837,7 +861,7 @@ void potrf_diag_kernel(double *__restrict__ Ablk, int64_t ld, int n_valid, int h
 	double *__restrict__ tinv, int *__restrict__ info, int64_t k0)
 {
 	extern __shared__ double sm[];
-	potrf_diag_body(Ablk, ld, n_valid, has_rhs, tinv, info, k0, sm);
+	potrf_diag_body<false>(Ablk, ld, n_valid, has_rhs, tinv, info, k0, sm);
 }
 
 
@@ -910,7 +934,9 @@ void update_potrf_kernel(int64_t M, int64_t N, const double *P, int64_t ld, doub
 		__syncthreads();
 		if(!go)
 			return;
-		potrf_diag_body(C, ld, n_valid, has_rhs, tinv, info, k0_next, sm);
+		// (a fence-free variant -- write-through stores of the sub-tiles, sc1 loads here: potrf_diag_body<true> -- measured
+		// the same within noise; the release / acquire pair is the form kept)
+		potrf_diag_body<false>(C, ld, n_valid, has_rhs, tinv, info, k0_next, sm);
 		return;
 	}
 	// the rest of the region in 64 x 64 blocks, block columns first
@@ -1066,12 +1092,16 @@ void trsv_back_chain_kernel(const double *__restrict__ R, int64_t ld, int64_t n,
 		part[h][r] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
 	}
 	__syncthreads();
+	// hand-off without a fence (MI355X_MICROARCH.md, valid forms: write-through payload on both sides): x_b is stored with
+	// agent-scope atomic (sc1) stores and read with agent-scope atomic loads, every storing wave drains its stores
+	// (s_waitcnt vmcnt(0)), the workgroup barrier orders them before the one relaxed flag store. The __threadfence() +
+	// release store this replaces wrote back and invalidated the L2 once per block row: ~4 us of the 8.5 us per hop.
 	if(tid < NB)
 		__hip_atomic_store(&xout[r0 + tid], part[0][tid] + part[1][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	__threadfence();
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	__syncthreads();
 	if(tid == 0)
-		__hip_atomic_store(&flags[b], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+		__hip_atomic_store(&flags[b], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __global__ void set_info_kernel(int *info) { info[0] = 0; info[1] = 0; }
