@@ -69,6 +69,18 @@ struct Structure {
 // ------------------------------------------------------------------------------------------------
 // Schur plan (guided ordering: poses first, landmarks last; LinearSolver_Schur.cpp:771-838)
 // ------------------------------------------------------------------------------------------------
+// one work item of the S accumulation: a chunk of the pair list of one block of S, with everything the wave
+// needs to finish it in ONE 32-byte (scalar) load -- the chain of dependent fetches per item (item -> block id
+// -> A offset / block coordinates -> A block) used to cost six memory round trips
+struct SaccItem {
+	int32_t beg, end;  // pair range
+	int32_t kind;      // 0: dp x dp block of the dense S at element offset dst (leading dimension ld),
+	                   // 1: contiguous dp*dp values at S + dst (sparse reduced system), 2: partial slot at partial + dst
+	int32_t pad;
+	int64_t dst;
+	int64_t aoff;      // offset of the A block in vals that this item adds, or -1
+};
+
 struct SchurPlan {
 	int dp = 0, dl = 0;            // pose / landmark block width
 	int64_t nc = 0, nl = 0;        // poses, landmarks owned by this shard
@@ -79,6 +91,7 @@ struct SchurPlan {
 	int64_t n_pairs = 0;           // sum_p k_p (k_p + 1) / 2
 	int64_t n_items = 0, n_multi = 0; // work items (block chunks) / blocks split over several items
 	bool add_A = true;             // this shard adds A and the pose rhs (rank 0)
+	bool u_landmark_major = true;  // layout of the packed U blocks (Up): observation order instead of camera-major
 	// reduced camera system kept SPARSE (block-CSC, dp x dp blocks) and solved by the supernodal path:
 	// S buffer = [ s_st.nvals block values | n_red reduced rhs ]
 	bool sparse_S = false;
@@ -102,11 +115,9 @@ struct SchurPlan {
 	DevBuf<int32_t> obs_wpos;      // [no] position of the observation in the per-pose (camera-major) lists:
 	                               //      W, Up and xw are stored camera-major (locality of the S accumulation)
 	// S accumulation work items
-	DevBuf<int32_t> item_blk;      // [n_items] S block id
-	DevBuf<int32_t> item_beg, item_end; // [n_items] pair range (items are ordered by camera tiles, not by block)
+	DevBuf<SaccItem> items;        // [n_items] (ordered by camera tiles, not by block)
 	DevBuf<int32_t> xcd_beg;       // [9] item range of each XCD (equal work, not equal counts)
 	int32_t xcd_max_items = 0;     // longest of those ranges
-	DevBuf<int32_t> item_slot;     // [n_items] -1: writes S directly, else partial slot
 	DevBuf<int32_t> sblk_i1, sblk_i2; // [n_sblk]
 	DevBuf<int64_t> sblk_aoff;     // [n_sblk] offset of the A block in vals or -1
 	DevBuf<int32_t> pair_a, pair_b; // [n_pairs]

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256)
 void obs_kernel(int64_t no, const int32_t *__restrict__ obs_lm, const int64_t *__restrict__ obs_off,
 	const int64_t *__restrict__ lm_rbase, const double *__restrict__ vals, const double *__restrict__ rhs,
 	const double *__restrict__ cinv, const int32_t *__restrict__ obs_wpos, double *__restrict__ W,
-	double *__restrict__ Up, double *__restrict__ xw)
+	double *__restrict__ Up, double *__restrict__ xw, int u_lm)
 {
 	constexpr int BLK = DP * DL, ST = BLK | 1;
 	__shared__ double img_all[4][64 * ST];
@@ -185,7 +185,7 @@ void obs_kernel(int64_t no, const int32_t *__restrict__ obs_lm, const int64_t *_
 	__syncthreads();
 	for(int p = lane; p < nact * BLK; p += 64) {
 		const int j = p / BLK, e = p - j * BLK;
-		Up[(int64_t)slot[j] * BLK + e] = img[j * ST + e];
+		Up[(u_lm ? a0 + j : (int64_t)slot[j]) * BLK + e] = img[j * ST + e]; // landmark-major = observation order
 	}
 	__syncthreads();
 #pragma unroll
@@ -198,7 +198,7 @@ void obs_kernel(int64_t no, const int32_t *__restrict__ obs_lm, const int64_t *_
 	}
 }
 
-// ---- S block accumulation: one wave per work item -------------------------------------------------
+// ---- S block accumulation: a wave works through a short run of work items ------------------------------
 // Each LANE takes whole pairs (a, b) of the item's list (lane, lane + 64, ...) and forms the DP x DP
 // outer product sum W_a U_b^T in registers (108 FMAs per pair). The blocks are NOT fetched by the lane
 // that consumes them: a lane-per-block gather makes every load instruction touch 64 different cache
@@ -209,19 +209,42 @@ void obs_kernel(int64_t no, const int32_t *__restrict__ obs_lm, const int64_t *_
 // own pair. The 64 partial blocks are summed IN LANE ORDER through LDS, so for lists of up to 64 pairs
 // (the common case) the additions happen in exactly the order of the pair list (= ascending landmark
 // = the reference's order); longer lists add lane-strided partial sums. No atomics: bit-reproducible.
-constexpr int SACC_WAVES = 4; // waves (items) per workgroup
+//
+// What bounds it (rocprofv3 counters, Venice shape, profiles/r02_venice871_s_accum_pmc.txt): the SIMDs' issue
+// ports. A wave lives ~15 500 cycles, a third of them issuing (640 vector + 137 LDS + 36 vector-memory
+// instructions per item of ~70 pairs), a third stalled behind the other wave of its SIMD, a third waiting for
+// memory; 8 waves per CU (LDS images + 232 VGPRs). The time did not follow the L2 misses (2.6e7 ... 4.0e7
+// 128-byte lines per launch across item orders: 0.85 ... 0.98 ms) nor a software pipeline across items.
+// Hence: (i) an item is ONE 32-byte record (SaccItem: pair range, destination, A offset) instead of four
+// dependent index loads, (ii) the block indices of a round are shuffled in one batch and every gather load is
+// unconditional (no branch per load), (iii) the reduction walks three segments of the partial list side by side
+// with 16-byte LDS reads. A wave can own `chunk` items, holding the pair indices of the NEXT round, the record
+// after that and the A block while a gather is in flight; with one item per wave (the default) that machinery
+// idles.
+constexpr int SACC_WAVES = 4; // waves per workgroup
 #ifndef SPP_SACC_RP
-#define SPP_SACC_RP 64 // 32 (half the LDS, twice the waves per CU) measured 14 % slower: the gather, not the occupancy, bounds the kernel
+#define SPP_SACC_RP 64 // pairs per round
 #endif
+
+__device__ __forceinline__ SaccItem sacc_load_item(const SaccItem *__restrict__ items, int32_t idx, int32_t lim)
+{
+	SaccItem r;
+	r.beg = r.end = 0;
+	r.kind = -1;
+	r.pad = 0;
+	r.dst = 0;
+	r.aoff = -1;
+	if(idx < lim)
+		r = items[idx];
+	return r;
+}
 
 template <int DP, int DL>
 __global__ __launch_bounds__(SACC_WAVES * 64)
-void s_accum_kernel(int64_t n_items, const int32_t *__restrict__ item_blk, const int32_t *__restrict__ item_beg,
-	const int32_t *__restrict__ item_end, const int32_t *__restrict__ xcd_beg, const int32_t *__restrict__ item_slot,
-	const int32_t *__restrict__ sblk_i1, const int32_t *__restrict__ sblk_i2,
-	const int64_t *__restrict__ sblk_aoff, const int32_t *__restrict__ pair_a, const int32_t *__restrict__ pair_b,
+void s_accum_kernel(const SaccItem *__restrict__ items, const int32_t *__restrict__ xcd_beg, int chunk,
+	const int32_t *__restrict__ pair_a, const int32_t *__restrict__ pair_b,
 	const double *__restrict__ W, const double *__restrict__ Up, const double *__restrict__ vals,
-	int add_A, double *__restrict__ S, int64_t ld, const int64_t *__restrict__ sblk_voff, double *__restrict__ partial)
+	double *__restrict__ S, int64_t ld, double *__restrict__ partial)
 {
 	constexpr int NE = DP * DP, BLK = DP * DL;
 	constexpr int PW = (BLK & 1) ? 1 : 2;       // doubles per fetched piece: 16-byte pieces need an even block (9-double
@@ -231,48 +254,84 @@ void s_accum_kernel(int64_t n_items, const int32_t *__restrict__ item_blk, const
 	constexpr int RP = SPP_SACC_RP;             // pairs per round: the LDS images hold RP blocks per operand
 	constexpr int NG = (RP + PPI - 1) / PPI;    // instructions per operand and round
 	constexpr int ST = BLK | 1;                 // LDS stride of one block image in doubles (odd)
-	constexpr int RS = (NE + 1) / 2 + 1;        // row stride of the reduction image
+	constexpr int NE2 = (NE + 1) / 2;           // element pairs of a block
+	constexpr int RS = 2 * NE2 + 2;             // row stride of the reduction image (even: 16-byte rows)
+	constexpr int NSEG = 64 / NE2 < 3 ? 64 / NE2 : 3; // segments of the partial list summed side by side
 	static_assert(2 * RP * ST >= RP * RS, "the reduction image reuses the staging area");
 	__shared__ double lds[SACC_WAVES][2 * RP * ST];
-	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
 	// workgroups go round-robin over the 8 XCDs: XCD x works through its own contiguous range of the
 	// items (equal work per range), so that the camera segments of a tile of blocks are fetched into
-	// ONE L2 (gridDim.x is a multiple of 8)
+	// ONE L2 (gridDim.x is a multiple of 8). A workgroup owns SACC_WAVES * chunk consecutive items of that
+	// range, wave w every SACC_WAVES-th of them.
 	const int x = blockIdx.x & 7;
-	const int64_t item = xcd_beg[x] + (int64_t)(blockIdx.x >> 3) * SACC_WAVES + wave;
-	if(item >= xcd_beg[x + 1])
+	const int32_t lim = xcd_beg[x + 1];
+	int32_t idx = xcd_beg[x] + (int32_t)(blockIdx.x >> 3) * SACC_WAVES * chunk + wave;
+	if(idx >= lim)
 		return; // whole wave
+	int left = chunk; // items this wave may still take
 	double *sw = lds[wave], *su = sw + RP * ST, *rw = sw;
-	const int32_t beg = item_beg[item], end = item_end[item];
 	const int my_pair = lane / PCS, my_piece = lane % PCS; // role in the cooperative fetch (lanes >= PPI * PCS idle)
+	SaccItem cur = sacc_load_item(items, idx, lim);
+	SaccItem nxt = sacc_load_item(items, (left > 1) ? idx + SACC_WAVES : lim, lim);
+	SaccItem nn = nxt;
+	int32_t q0 = cur.beg;
+	int32_t pa = -1, pb = -1;
+	if(lane < RP && q0 + lane < cur.end) {
+		pa = pair_a[q0 + lane];
+		pb = pair_b[q0 + lane];
+	}
 	double acc[NE];
 #pragma unroll
 	for(int e = 0; e < NE; ++ e)
 		acc[e] = 0;
-	for(int32_t q0 = beg; q0 < end; q0 += RP) {
-		const int32_t q = q0 + lane;
-		const bool mine = lane < RP && q < end; // this lane owns a pair of the round
-		const int32_t pa = mine ? pair_a[q] : -1, pb = mine ? pair_b[q] : -1;
+	for(;;) {
+		const int nround = (cur.end - q0 < RP) ? cur.end - q0 : RP; // 0 for an item without pairs (A only)
+		const bool mine = lane < nround; // this lane owns a pair of the round
+		const bool last = q0 + RP >= cur.end; // last round of the item (wave-uniform)
+		// ---- ahead of this round's gather: the pair indices of the next round, and at the end of an item the
+		// record after the next one and this item's A block
+		const int32_t nq0 = last ? nxt.beg : q0 + RP, nend = last ? nxt.end : cur.end;
+		int32_t pa_n = -1, pb_n = -1;
+		if(lane < RP && nq0 + lane < nend) {
+			pa_n = pair_a[nq0 + lane];
+			pb_n = pair_b[nq0 + lane];
+		}
+		double aval0 = 0, aval1 = 0;
+		if(last) {
+			nn = sacc_load_item(items, (left > 2) ? idx + 2 * SACC_WAVES : lim, lim);
+			if(cur.aoff >= 0 && lane < NE2) {
+				aval0 = vals[cur.aoff + 2 * lane];
+				if(2 * lane + 1 < NE)
+					aval1 = vals[cur.aoff + 2 * lane + 1];
+			}
+		}
 		// ---- cooperative fetch of up to 64 W and 64 U blocks into the LDS images
-		const int nround = (end - q0 < RP) ? end - q0 : RP;
 		constexpr int GC = (NG < 10) ? NG : 10; // groups in flight at a time (register budget of the 6 x 6 case)
 #pragma unroll
 		for(int g0 = 0; g0 < NG; g0 += GC) {
+			// block indices first -- one ds_bpermute each, all in flight together --, then the loads, none of them
+			// behind a branch: a lane without a pair to serve (short round, the idle lanes behind PPI * PCS) fetches
+			// from block 0 and its piece of the image is never read
+			int32_t ia[GC], ib[GC];
+#pragma unroll
+			for(int gg = 0; gg < GC; ++ gg) {
+				const int p = (g0 + gg) * PPI + my_pair; // pair of this round served by this lane
+				ia[gg] = __shfl(pa, p & 63);
+				ib[gg] = __shfl(pb, p & 63);
+			}
 			double tw[GC][PW], tu[GC][PW];
 #pragma unroll
 			for(int gg = 0; gg < GC; ++ gg) {
-				const int g = g0 + gg;
-				const int p = g * PPI + my_pair; // pair of this round served by this lane
-				const int32_t ia = __shfl(pa, p & 63), ib = __shfl(pb, p & 63);
-				const bool on = g < NG && my_pair < PPI && p < nround;
+				int32_t xa = ia[gg] < 0 ? 0 : ia[gg], xb = ib[gg] < 0 ? 0 : ib[gg];
 				if(PW == 2) {
-					const double2 a2 = on ? *(const double2*)(W + (int64_t)ia * BLK + 2 * my_piece) : make_double2(0, 0);
-					const double2 b2 = on ? *(const double2*)(Up + (int64_t)ib * BLK + 2 * my_piece) : make_double2(0, 0);
+					const double2 a2 = *(const double2*)(W + (int64_t)xa * BLK + 2 * my_piece);
+					const double2 b2 = *(const double2*)(Up + (int64_t)xb * BLK + 2 * my_piece);
 					tw[gg][0] = a2.x; tw[gg][PW - 1] = a2.y;
 					tu[gg][0] = b2.x; tu[gg][PW - 1] = b2.y;
 				} else {
-					tw[gg][0] = on ? W[(int64_t)ia * BLK + my_piece] : 0.0;
-					tu[gg][0] = on ? Up[(int64_t)ib * BLK + my_piece] : 0.0;
+					tw[gg][0] = W[(int64_t)xa * BLK + my_piece];
+					tu[gg][0] = Up[(int64_t)xb * BLK + my_piece];
 				}
 			}
 #pragma unroll
@@ -311,61 +370,89 @@ void s_accum_kernel(int64_t n_items, const int32_t *__restrict__ item_blk, const
 		}
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 		__builtin_amdgcn_wave_barrier();
-	}
-	int nact = end - beg;
-	if(nact > RP)
-		nact = RP;
-	// in-order reduction through LDS in two halves of the block
-	double sum = 0;
+		if(last) {
+			int nact = cur.end - cur.beg;
+			if(nact > RP)
+				nact = RP;
+			// Reduction of the partial blocks through LDS. The lanes that own no pair hold exact zeros. Lane (e2, q)
+			// adds elements 2 e2, 2 e2 + 1 of the q-th segment of the partial list in list order; the NSEG segment
+			// sums are then added in order: a fixed summation order (bit-reproducible), with a dependent chain a
+			// third as long as one lane walking the whole list.
 #pragma unroll
-	for(int h = 0; h < 2; ++ h) {
-		constexpr int H0 = (NE + 1) / 2;
-		const int e0 = h ? H0 : 0, ne = h ? NE - H0 : H0;
-		if(lane < nact) {
+			for(int e = 0; e < NE; ++ e)
+				rw[lane * RS + e] = acc[e];
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			const int seg_len = (nact + NSEG - 1) / NSEG;
+			const int e2 = lane % NE2, sq = lane / NE2;
+			double s0 = 0, s1 = 0;
+			if(sq < NSEG) {
+				const double *src = rw + (sq * seg_len) * RS + 2 * e2;
+				const int len = (seg_len < RP - sq * seg_len) ? seg_len : RP - sq * seg_len; // rows [nact, RP) are zeros
+				int l = 0;
+				for(; l + 8 <= len; l += 8) {
+					double2 t[8];
 #pragma unroll
-			for(int e = 0; e < H0; ++ e)
-				if(e < ne)
-					rw[lane * RS + e] = acc[e0 + e];
-		}
-		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-		if(lane >= e0 && lane < e0 + ne) { // lane e owns element e of the block
-			const int e = lane - e0;
-			double sacc = 0; // strictly in lane order; the loads of 8 partial blocks are in flight together
-			int l = 0;
-			for(; l + 8 <= nact; l += 8) {
-				double t[8];
+					for(int u = 0; u < 8; ++ u)
+						t[u] = *(const double2*)(src + (l + u) * RS);
 #pragma unroll
-				for(int u = 0; u < 8; ++ u)
-					t[u] = rw[(l + u) * RS + e];
-#pragma unroll
-				for(int u = 0; u < 8; ++ u)
-					sacc += t[u];
+					for(int u = 0; u < 8; ++ u) {
+						s0 += t[u].x;
+						s1 += t[u].y;
+					}
+				}
+				for(; l < len; ++ l) {
+					const double2 t = *(const double2*)(src + l * RS);
+					s0 += t.x;
+					s1 += t.y;
+				}
 			}
-			for(; l < nact; ++ l)
-				sacc += rw[l * RS + e];
-			sum = sacc;
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			{
+				const double g0 = s0, g1 = s1; // the segment sums as they are before any lane combines them
+#pragma unroll
+				for(int q = 1; q < NSEG; ++ q) {
+					s0 += __shfl(g0, (lane + q * NE2) & 63); // only lanes < NE2 keep a meaningful result
+					s1 += __shfl(g1, (lane + q * NE2) & 63);
+				}
+			}
+			if(lane < NE2) {
+				const int e = 2 * lane;
+				const bool two = e + 1 < NE;
+				double *dst;
+				int64_t o0 = e, o1 = e + 1;
+				if(cur.kind == 2)
+					dst = partial + cur.dst;
+				else {
+					dst = S + cur.dst;
+					if(cur.aoff >= 0) { // AddTo_FBS: S = A + W V
+						s0 = aval0 + s0;
+						s1 = aval1 + s1;
+					}
+					if(cur.kind == 0) { // dp x dp block of the dense S
+						o0 = e % DP + (e / DP) * ld;
+						o1 = (e + 1) % DP + ((e + 1) / DP) * ld;
+					}
+				}
+				dst[o0] = s0;
+				if(two)
+					dst[o1] = s1;
+			}
+#pragma unroll
+			for(int e = 0; e < NE; ++ e)
+				acc[e] = 0;
+			idx += SACC_WAVES;
+			-- left;
+			cur = nxt;
+			nxt = nn;
+			if(left == 0 || cur.kind < 0)
+				break;
 		}
-		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-		__builtin_amdgcn_wave_barrier();
+		q0 = nq0;
+		pa = pa_n;
+		pb = pb_n;
 	}
-	if(lane >= NE)
-		return;
-	const int32_t b = item_blk[item];
-	const int32_t slot = item_slot[item];
-	if(slot >= 0) {
-		partial[(int64_t)slot * NE + lane] = sum;
-		return;
-	}
-	const int64_t aoff = sblk_aoff[b];
-	if(add_A && aoff >= 0)
-		sum = vals[aoff + lane] + sum; // AddTo_FBS: S = A + W V
-	if(sblk_voff) { // sparse reduced system: dp x dp column-major block in the value array
-		S[sblk_voff[b] + lane] = sum;
-		return;
-	}
-	const int r = lane % DP, c = lane / DP;
-	S[((int64_t)sblk_i1[b] * DP + r) + ((int64_t)sblk_i2[b] * DP + c) * ld] = sum;
 }
 
 // blocks whose pair list was split: sum the partial slots in order (+ A)
@@ -526,13 +613,25 @@ static void schur_form_t(spp_ctx *ctx, const double *d_vals, const double *d_rhs
 			sp.nl, sp.lm_coff.p, d_vals, sp.cinv.p);
 	if(sp.no)
 		hipLaunchKernelGGL((obs_kernel<DP, DL>), dim3((unsigned)((sp.no + 255) / 256)), dim3(256), 0, s,
-			sp.no, sp.obs_lm.p, sp.obs_off.p, sp.lm_rbase.p, d_vals, d_rhs, sp.cinv.p, sp.obs_wpos.p, sp.W.p, sp.Up.p, sp.xw.p);
+			sp.no, sp.obs_lm.p, sp.obs_off.p, sp.lm_rbase.p, d_vals, d_rhs, sp.cinv.p, sp.obs_wpos.p, sp.W.p, sp.Up.p, sp.xw.p, sp.u_landmark_major ? 1 : 0);
 	phase_end(ctx, SPP_PHASE_SCHUR_INV);
 	phase_begin(ctx, SPP_PHASE_SCHUR_GEMM);
-	if(sp.n_items)
-		hipLaunchKernelGGL((s_accum_kernel<DP, DL>), dim3((unsigned)(8 * ((sp.xcd_max_items + SACC_WAVES - 1) / SACC_WAVES))), dim3(SACC_WAVES * 64), 0, s,
-			sp.n_items, sp.item_blk.p, sp.item_beg.p, sp.item_end.p, sp.xcd_beg.p, sp.item_slot.p, sp.sblk_i1.p, sp.sblk_i2.p, sp.sblk_aoff.p,
-			sp.pair_a.p, sp.pair_b.p, sp.W.p, sp.Up.p, d_vals, sp.add_A ? 1 : 0, S, ld, voff, sp.partial.p);
+	if(sp.n_items) {
+		static int chunk_env = -1;
+		if(chunk_env < 0) {
+			// items per wave (0 = one persistent set of workgroups). Measured on the Venice shape: 1 -> 0.86 ms, 4...16 ->
+			// 0.98 ms, persistent 1.5 ms: the hardware's dynamic dispatch of one-item waves balances the uneven items
+			// (1 ... 2048 pairs) better than the software pipeline across items hides latency
+			const char *e = getenv("SPP_SACC_CHUNK");
+			chunk_env = e ? atoi(e) : 1;
+		}
+		int chunk = chunk_env;
+		if(chunk <= 0) // persistent: two workgroups per CU (the LDS images of 8 waves fill a CU)
+			chunk = (int)((sp.xcd_max_items + SACC_WAVES * 64 - 1) / (SACC_WAVES * 64));
+		const int64_t per = (int64_t)SACC_WAVES * chunk;
+		hipLaunchKernelGGL((s_accum_kernel<DP, DL>), dim3((unsigned)(8 * ((sp.xcd_max_items + per - 1) / per))), dim3(SACC_WAVES * 64), 0, s,
+			sp.items.p, sp.xcd_beg.p, chunk, sp.pair_a.p, sp.pair_b.p, sp.W.p, sp.Up.p, d_vals, S, ld, sp.partial.p);
+	}
 	if(sp.n_multi)
 		hipLaunchKernelGGL((s_multi_kernel<DP>), dim3((unsigned)((sp.n_multi + 3) / 4)), dim3(256), 0, s,
 			sp.n_multi, sp.multi_blk.p, sp.multi_ptr.p, sp.sblk_i1.p, sp.sblk_i2.p, sp.sblk_aoff.p,

@@ -23,8 +23,8 @@ namespace spp {
 void SchurPlan::release_all()
 {
 	lm_ptr.release(); lm_coff.release(); lm_rbase.release(); obs_pose.release(); obs_lm.release();
-	obs_off.release(); pose_rbase.release(); cam_ptr.release(); cam_obs.release(); item_blk.release();
-	item_beg.release(); item_end.release(); obs_wpos.release(); xcd_beg.release(); item_slot.release(); sblk_i1.release(); sblk_i2.release(); sblk_aoff.release();
+	obs_off.release(); pose_rbase.release(); cam_ptr.release(); cam_obs.release(); items.release();
+	obs_wpos.release(); xcd_beg.release(); sblk_i1.release(); sblk_i2.release(); sblk_aoff.release();
 	sblk_voff.release(); s_st = Structure(); sparse_S = false; mis = false;
 	pair_a.release(); pair_b.release(); multi_blk.release(); multi_ptr.release(); cinv.release();
 	W.release(); Up.release(); xw.release(); partial.release(); S.release();
@@ -344,6 +344,7 @@ void build_schur_plan(spp_ctx *ctx, bool sparse_S, bool mis)
 	// ---- sparse reduced system: the written blocks of S as an upper block-CSC structure (columns = i2,
 	// rows i1 ascending, diagonal last): the block list above is row-major, a counting sort by column
 	// keeps the rows ascending
+	std::vector<int64_t> sblk_voff_h; // host copy for the item records
 	if(sparse_S) {
 		Structure &ss = sp.s_st;
 		ss.nb = nc;
@@ -372,12 +373,20 @@ void build_schur_plan(spp_ctx *ctx, bool sparse_S, bool mis)
 			SPP_REQUIRE(ss.col_ptr[c + 1] > ss.col_ptr[c] && ss.row_idx[ss.col_ptr[c + 1] - 1] == c, SPP_E_BADARG,
 				"a pose without any diagonal contribution: the reduced system is singular");
 		sp.sblk_voff.upload(voff, s);
+		sblk_voff_h.swap(voff);
 	}
 
 	// the pair lists address W / Up, i.e. camera-major positions
+	// (the packed U either camera-major like W, or landmark-major = in observation order: the blocks of one
+	// landmark's observers are then one contiguous run, which the blocks of one ROW of S gather together)
+	{
+		const char *e = getenv("SPP_SACC_ULM");
+		sp.u_landmark_major = e ? atoi(e) != 0 : true;
+	}
 	for(int64_t q = 0; q < n_pairs; ++ q) {
 		pair_a[q] = wpos[pair_a[q]];
-		pair_b[q] = wpos[pair_b[q]];
+		if(!sp.u_landmark_major)
+			pair_b[q] = wpos[pair_b[q]];
 	}
 
 	// ---- work items: chunks of at most PAIR_CHUNK pairs
@@ -402,20 +411,52 @@ void build_schur_plan(spp_ctx *ctx, bool sparse_S, bool mis)
 	// the W segments of the tile's row cameras and the U segments of its column cameras (~0.5 MB each
 	// on Venice) then stay in the L2 of the XCD that works through the tile (the kernel hands each XCD
 	// one contiguous range of items).
+	bool interleave = false;
+	std::vector<int32_t> xb_il;
 	{
 		static int64_t tb_env = -1;
 		if(tb_env < 0) {
 			const char *e = getenv("SPP_SACC_TILE"); // cameras per side of an item tile (1 = plain row-major block order)
 			tb_env = e ? std::max<int64_t>(1, atol(e)) : 4;
 		}
-		const int64_t TB = tb_env, ntile = (nc + TB - 1) / TB;
+		static int64_t tbc_env = -1;
+		if(tbc_env < 0) {
+			const char *e = getenv("SPP_SACC_TILE_COLS"); // cameras per tile along a row of S (0: the whole row)
+			tbc_env = e ? atol(e) : -2;
+		}
+		const int64_t TB = tb_env, TBC = (tbc_env == -2) ? TB : (tbc_env <= 0 ? nc : tbc_env), ntile = (nc + TBC - 1) / TBC;
 		std::vector<int32_t> perm(item_blk.size());
 		for(size_t q = 0; q < perm.size(); ++ q)
 			perm[q] = (int32_t)q;
-		std::stable_sort(perm.begin(), perm.end(), [&](int32_t x, int32_t y) {
-			const int64_t kx = (sblk_i1[item_blk[x]] / TB) * ntile + sblk_i2[item_blk[x]] / TB;
-			const int64_t ky = (sblk_i1[item_blk[y]] / TB) * ntile + sblk_i2[item_blk[y]] / TB;
-			return kx < ky; });
+		static int il_env = -1;
+		if(il_env < 0) {
+			const char *e = getenv("SPP_SACC_XCD"); // 1: tiles dealt round-robin to the XCDs, 0: one contiguous range per XCD
+			il_env = e ? atoi(e) : 1;
+		}
+		interleave = il_env != 0;
+		auto tile_of = [&](int32_t q) { return (sblk_i1[item_blk[q]] / TB) * ntile + sblk_i2[item_blk[q]] / TBC; };
+		std::stable_sort(perm.begin(), perm.end(), [&](int32_t x, int32_t y) { return tile_of(x) < tile_of(y); });
+		if(interleave) {
+			// All eight XCDs work in the same neighbourhood of S: consecutive tiles (in tile-row-major order) go to
+			// consecutive XCDs. A tile's camera segments still meet in ONE L2, and the blocks every XCD re-reads
+			// within a band of S now share one working set in the memory-side cache (256 MB) instead of eight.
+			std::vector<int64_t> rank(perm.size()); // running index of the item's tile among the non-empty tiles
+			int64_t r = -1, prev = -1;
+			for(size_t q = 0; q < perm.size(); ++ q) {
+				const int64_t t = tile_of(perm[q]);
+				if(t != prev) {
+					++ r;
+					prev = t;
+				}
+				rank[perm[q]] = r;
+			}
+			std::stable_sort(perm.begin(), perm.end(), [&](int32_t x, int32_t y) { return (rank[x] & 7) < (rank[y] & 7); });
+			xb_il.assign(9, 0);
+			for(size_t q = 0; q < perm.size(); ++ q)
+				++ xb_il[(rank[q] & 7) + 1];
+			for(int x = 0; x < 8; ++ x)
+				xb_il[x + 1] += xb_il[x];
+		}
 		std::vector<int32_t> t_blk(perm.size()), t_beg(perm.size()), t_end(perm.size()), t_slot(perm.size());
 		for(size_t q = 0; q < perm.size(); ++ q) {
 			t_blk[q] = item_blk[perm[q]];
@@ -426,16 +467,20 @@ void build_schur_plan(spp_ctx *ctx, bool sparse_S, bool mis)
 		item_blk.swap(t_blk); item_beg.swap(t_beg); item_end.swap(t_end); item_slot.swap(t_slot);
 	}
 	sp.n_items = (int64_t)item_blk.size();
-	// eight contiguous item ranges of equal WORK (one per XCD): a wave spends a fixed cost per item plus
+	// eight item ranges (one per XCD). Contiguous ranges: of equal WORK -- a wave spends a fixed cost per item plus
 	// one gather round per 64 pairs; equal item counts would leave the last range ~45 % heavier
 	{
-		std::vector<int64_t> cost(sp.n_items + 1, 0);
-		for(int64_t q = 0; q < sp.n_items; ++ q)
-			cost[q + 1] = cost[q] + 2 + (item_end[q] - item_beg[q] + 63) / 64;
 		std::vector<int32_t> xb(9, 0);
-		for(int x = 1; x < 8; ++ x)
-			xb[x] = (int32_t)(std::lower_bound(cost.begin(), cost.end(), cost[sp.n_items] * x / 8) - cost.begin());
-		xb[8] = (int32_t)sp.n_items;
+		if(interleave)
+			xb = xb_il;
+		else {
+			std::vector<int64_t> cost(sp.n_items + 1, 0);
+			for(int64_t q = 0; q < sp.n_items; ++ q)
+				cost[q + 1] = cost[q] + 2 + (item_end[q] - item_beg[q] + 63) / 64;
+			for(int x = 1; x < 8; ++ x)
+				xb[x] = (int32_t)(std::lower_bound(cost.begin(), cost.end(), cost[sp.n_items] * x / 8) - cost.begin());
+			xb[8] = (int32_t)sp.n_items;
+		}
 		sp.xcd_max_items = 0;
 		for(int x = 0; x < 8; ++ x) {
 			xb[x + 1] = std::max(xb[x + 1], xb[x]);
@@ -462,11 +507,33 @@ void build_schur_plan(spp_ctx *ctx, bool sparse_S, bool mis)
 	sp.pose_rbase.upload(pose_rbase, s);
 	sp.cam_ptr.upload(cam_ptr, s);
 	sp.cam_obs.upload(cam_obs, s);
-	sp.item_blk.upload(item_blk, s);
-	sp.item_beg.upload(item_beg, s);
-	sp.item_end.upload(item_end, s);
+	{
+		// self-contained item records (one 32-byte load per item in the kernel)
+		std::vector<SaccItem> recs(item_blk.size());
+		for(size_t q = 0; q < recs.size(); ++ q) {
+			const int32_t b = item_blk[q];
+			SaccItem &r = recs[q];
+			r.beg = item_beg[q];
+			r.end = item_end[q];
+			r.pad = 0;
+			r.aoff = -1;
+			if(item_slot[q] >= 0) { // split block: s_multi_kernel sums the slots and adds A
+				r.kind = 2;
+				r.dst = (int64_t)item_slot[q] * dp * dp;
+			} else {
+				r.aoff = sp.add_A ? sblk_aoff[b] : -1;
+				if(sparse_S) {
+					r.kind = 1;
+					r.dst = sblk_voff_h[b];
+				} else {
+					r.kind = 0;
+					r.dst = (int64_t)sblk_i1[b] * dp + (int64_t)sblk_i2[b] * dp * sp.ld;
+				}
+			}
+		}
+		sp.items.upload(recs, s);
+	}
 	sp.obs_wpos.upload(wpos, s);
-	sp.item_slot.upload(item_slot, s);
 	sp.sblk_i1.upload(sblk_i1, s);
 	sp.sblk_i2.upload(sblk_i2, s);
 	sp.sblk_aoff.upload(sblk_aoff, s);

@@ -1,0 +1,30 @@
+#!/bin/bash
+# counters of one kernel (substring $1) over a short bench run: one rocprofv3 --pmc pass per counter group
+# (--kernel-trace only beside --pmc), averaged per launch.  tools/pmc_kernel.sh s_accum_kernel [workload] [groups]
+# (the TA_* counters abort rocprofv3 on this image: not used)
+k=$1; w=${2:-venice871}; sel=${3:-"1 2 3"}
+out=$PWD/gpurun_out/pmc_$k; rm -rf $out; mkdir -p $out; export TMPDIR=/tmp
+grp[1]="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"
+grp[2]="SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
+grp[3]="TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum"
+grp[4]="FETCH_SIZE"
+grp[5]="WRITE_SIZE"
+for i in $sel; do
+  timeout -k 10 120 rocprofv3 --kernel-trace --pmc ${grp[$i]} -d $out/p$i -o run --output-format csv -- python3 bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --cpu-cholmod off > $out/p$i.log 2>&1 || { echo "pass $i failed"; exit 1; }
+done
+python3 - "$out" "$k" <<'PY'
+import sys,glob,csv,collections
+out,k=sys.argv[1:3]
+dur=collections.defaultdict(lambda:[0,0.0])
+for f in sorted(glob.glob(out+"/p*/**/*_kernel_trace.csv",recursive=True))[:1]:
+    for r in csv.DictReader(open(f)):
+        if k in r["Kernel_Name"]:
+            d=dur[r["Kernel_Name"][:60]]; d[0]+=1; d[1]+=(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3
+for n,(c,s) in dur.items(): print("%-60s launches %3d avg %.1f us (under pmc)"%(n,c,s/c))
+for f in sorted(glob.glob(out+"/p*/**/*_counter_collection.csv",recursive=True)):
+    acc=collections.defaultdict(lambda:[0,0.0])
+    for r in csv.DictReader(open(f)):
+        if k in r["Kernel_Name"]:
+            a=acc[r["Counter_Name"]]; a[0]+=1; a[1]+=float(r["Counter_Value"])
+    for c,(n,s) in acc.items(): print("%-36s launches %3d avg %.6g"%(c,n,s/n))
+PY
