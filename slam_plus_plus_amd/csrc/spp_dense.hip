@@ -1127,7 +1127,8 @@ void dense_set_padding(spp_ctx *ctx, double *d_A, int64_t ld, int64_t n)
 // host drivers
 // --------------------------------------------------------------------------------------------------
 // info[0]: first failing pivot + 1, info[1]: timeout of the backward-substitution chain, info[2]: abort flag of
-// the device-flag hand-offs (stays set until the host has seen it) -- zeroed once, when the buffer is created
+// the device-flag hand-offs (stays set until the host has seen it), info[3]: abort flag of the sparse path's
+// dependency-driven launches -- zeroed once, when the buffer is created
 static void ensure_info(spp_ctx *ctx)
 {
 	if(!ctx->dense.info.p) {
@@ -1705,9 +1706,15 @@ void dense_chain_check(spp_ctx *ctx)
 
 int dense_info_fetch(spp_ctx *ctx)
 {
-	int h_info[3] = {0, 0, 0};
-	SPP_HIP_CHECK(hipMemcpyAsync(h_info, ctx->dense.info.p, 3 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+	int h_info[4] = {0, 0, 0, 0};
+	SPP_HIP_CHECK(hipMemcpyAsync(h_info, ctx->dense.info.p, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
 	SPP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	if(h_info[3]) { // a front of the dependency-driven sparse launches timed out waiting for a child / its parent
+		SPP_HIP_CHECK(hipMemset(ctx->dense.info.p + 3, 0, sizeof(int)));
+		sparse_dag_disable(ctx);
+		throw Error(SPP_E_HIP, "sparse factorization: a front timed out waiting for another front's flag; "
+			"the following calls launch level by level");
+	}
 	if(h_info[2]) { // a cross-stream flag wait timed out: the result is garbage, the flag hand-offs stay off
 		SPP_HIP_CHECK(hipMemset(ctx->dense.info.p + 2, 0, sizeof(int)));
 		ctx->dense.sync_state = -1;

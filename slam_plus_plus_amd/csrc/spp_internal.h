@@ -241,6 +241,7 @@ bool schur_applicable(const Structure &st, int *dp, int *dl);
 void sparse_analyze(spp_ctx *ctx, const Structure &st); // plan for `st` (Lambda, or the sparse reduced system)
 int sparse_factor_solve(spp_ctx *ctx, const double *d_vals, double *d_rhs);
 void sparse_release(spp_ctx *ctx);
+void sparse_dag_disable(spp_ctx *ctx); // after a timed-out flag wait: level-by-level launches from then on
 int64_t sparse_info(const spp_ctx *ctx, int what);
 
 // ---- spp_schur.hip ----

@@ -77,6 +77,14 @@ struct SparsePlan {
 	DevBuf<int32_t> perm_scalar;               // [n] permuted scalar -> original scalar
 	DevBuf<double> fronts, vbuf, xperm;
 	DevBuf<int> info;
+	// dependency-driven launches (front_dag_kernel): the fronts of levels < dag_level_limit, children first
+	DevBuf<int32_t> front_cls, front_parent, front_level; // [ns]
+	DevBuf<int32_t> dag_list, dag_list_bwd;    // dispatch order of the factorization / of the backward substitution
+	DevBuf<int> dag_done;                      // [ns] epoch flags
+	int32_t dag_n = 0, dag_level_limit = 0;
+	int dag_epoch = 0;
+	size_t dag_lds = 0;                        // dynamic LDS of the factorization launch (largest class present)
+	bool dag_ok = true;                        // false after a timed-out wait: level-by-level launches from then on
 };
 
 // --------------------------------------------------------------------------------------------------
@@ -162,6 +170,12 @@ void sparse_release(spp_ctx *ctx)
 {
 	delete ctx->sparse;
 	ctx->sparse = nullptr;
+}
+
+void sparse_dag_disable(spp_ctx *ctx)
+{
+	if(ctx->sparse)
+		ctx->sparse->dag_ok = false;
 }
 
 int64_t sparse_info(const spp_ctx *ctx, int what)
@@ -459,6 +473,29 @@ void sparse_analyze(spp_ctx *ctx, const Structure &st)
 				max_steps = std::max<int64_t>(max_steps, (front_w[q] + front_pad[q]) / DENSE_NB);
 		dense_reserve(ctx, max_steps);
 	}
+	// dependency-driven part: every level below the first one that holds a big (multi-kernel) front
+	std::vector<int32_t> dag_list, dag_list_bwd;
+	{
+		int32_t limit = (int32_t)sp->n_levels;
+		for(int64_t q = 0; q < ns; ++ q)
+			if(front_cls[q] == 4)
+				limit = std::min(limit, level[q]);
+		sp->dag_level_limit = limit;
+		int max_cls = 0;
+		for(int64_t q = 0; q < ns; ++ q)
+			if(level[q] < limit) {
+				dag_list.push_back((int32_t)q);
+				max_cls = std::max(max_cls, front_cls[q]);
+			}
+		// children first; inside a level the long fronts (large classes) first
+		std::stable_sort(dag_list.begin(), dag_list.end(), [&](int32_t a, int32_t b) {
+			return level[a] != level[b] ? level[a] < level[b] : front_cls[a] > front_cls[b]; });
+		dag_list_bwd.assign(dag_list.rbegin(), dag_list.rend()); // parents first
+		sp->dag_n = (int32_t)dag_list.size();
+		const size_t hp = max_cls == 0 ? 32 : (max_cls == 1 ? 64 : (max_cls == 2 ? 128 : MID_FRONT_MAX));
+		sp->dag_lds = ((max_cls == 3 ? std::max<size_t>((size_t)17 * MID_FRONT_MAX + MID_FRONT_MAX, (size_t)128 * 129 + 128) : hp * (hp + 1) + hp)
+			+ 2 * 16 * PT + 8) * sizeof(double);
+	}
 	sp->h_front_ld = front_ld;
 	sp->h_front_pad = front_pad;
 	sp->h_front_cls = front_cls;
@@ -589,6 +626,14 @@ void sparse_analyze(spp_ctx *ctx, const Structure &st)
 	sp->rows_ptr.upload(rows_ptr, s);
 	sp->rows.upload(rows, s);
 	sp->perm_scalar.upload(perm_scalar, s);
+	sp->front_cls.upload(front_cls, s);
+	sp->front_parent.upload(sn_parent, s);
+	sp->front_level.upload(level, s);
+	sp->dag_list.upload(dag_list, s);
+	sp->dag_list_bwd.upload(dag_list_bwd, s);
+	sp->dag_done.reserve((size_t)std::max<int64_t>(ns, 1));
+	SPP_HIP_CHECK(hipMemsetAsync(sp->dag_done.p, 0, (size_t)std::max<int64_t>(ns, 1) * sizeof(int), s));
+	sp->dag_epoch = 0;
 	sp->fronts.reserve((size_t)std::max<int64_t>(foff, 2));
 	sp->vbuf.reserve((size_t)std::max<int64_t>(voff, 1));
 	sp->xperm.reserve((size_t)st.n);
@@ -609,21 +654,37 @@ __device__ __forceinline__ int padded(int r, int w, int pad) { return r < w ? r 
 //         B  row panel X = Dinv^T Y, one 16 x 16 MFMA tile per wave
 //         C  trailing update T[I,K] -= P_I^T P_K on MFMA f64 16x16x4
 // The result is written back to the front's HBM buffer in the plain (unpadded) layout.
+// the arrays of the plan the frontal kernels read (one struct: the same argument block for every kernel)
+struct FrontArgs {
+	const int64_t *front_off;
+	const int32_t *front_h, *front_w, *front_ld, *front_pad;
+	const int32_t *asm_ptr;
+	const int64_t *asm_src;
+	const int32_t *asm_dst, *asm_shape, *child_ptr, *child_list, *rel_ptr, *rel, *rows_ptr, *rows;
+	const int64_t *front_voff;
+	double *xperm;
+	const double *vals;
+	double *fronts, *vbuf;
+	int *info;
+};
+
 template <int HP, int NTH, bool GMEM>
-__global__ __launch_bounds__(NTH)
-void front_lds_kernel(const int32_t *__restrict__ list, const int64_t *__restrict__ front_off,
-	const int32_t *__restrict__ front_h, const int32_t *__restrict__ front_w, const int32_t *__restrict__ front_ld,
-	const int32_t *__restrict__ front_pad, const int32_t *__restrict__ asm_ptr, const int64_t *__restrict__ asm_src,
-	const int32_t *__restrict__ asm_dst, const int32_t *__restrict__ asm_shape, const int32_t *__restrict__ child_ptr,
-	const int32_t *__restrict__ child_list, const int32_t *__restrict__ rel_ptr, const int32_t *__restrict__ rel,
-	const int32_t *__restrict__ rows_ptr, const int32_t *__restrict__ rows, const double *__restrict__ xperm,
-	const double *__restrict__ vals, double *__restrict__ fronts, int *__restrict__ info)
+__device__ __forceinline__ void front_body(const int s, const FrontArgs &fa, double *fsm)
 {
+	const int64_t *__restrict__ front_off = fa.front_off;
+	const int32_t *__restrict__ front_h = fa.front_h, *__restrict__ front_w = fa.front_w, *__restrict__ front_ld = fa.front_ld;
+	const int32_t *__restrict__ front_pad = fa.front_pad, *__restrict__ asm_ptr = fa.asm_ptr;
+	const int64_t *__restrict__ asm_src = fa.asm_src;
+	const int32_t *__restrict__ asm_dst = fa.asm_dst, *__restrict__ asm_shape = fa.asm_shape, *__restrict__ child_ptr = fa.child_ptr;
+	const int32_t *__restrict__ child_list = fa.child_list, *__restrict__ rel_ptr = fa.rel_ptr, *__restrict__ rel = fa.rel;
+	const int32_t *__restrict__ rows_ptr = fa.rows_ptr, *__restrict__ rows = fa.rows;
+	const double *xperm = fa.xperm;
+	const double *__restrict__ vals = fa.vals;
+	double *fronts = fa.fronts;
+	int *info = fa.info;
 	// GMEM: the image is the front's own HBM buffer (already in the 16-padded layout, stride ld);
 	// otherwise an LDS image of HP x (HP + 1) doubles
 	constexpr int NW = NTH / 64;
-	extern __shared__ double fsm[];
-	const int s = list[blockIdx.x];
 	const int h = front_h[s], w = front_w[s], ld = front_ld[s];
 	const int w16 = (w + 15) & ~15, pad = w16 - w, hp = h + pad, nt = (hp + 15) >> 4;
 	double *F = fronts + front_off[s];
@@ -813,6 +874,14 @@ void front_lds_kernel(const int32_t *__restrict__ list, const int64_t *__restric
 	}
 }
 
+template <int HP, int NTH, bool GMEM>
+__global__ __launch_bounds__(NTH)
+void front_lds_kernel(const int32_t *__restrict__ list, FrontArgs fa)
+{
+	extern __shared__ double fsm[];
+	front_body<HP, NTH, GMEM>(list[blockIdx.x], fa, fsm);
+}
+
 // ---- big fronts (image does not fit LDS): assembled in HBM in the padded layout, factored by the
 // multi-workgroup dense kernels (spp_dense.hip). ONE launch assembles a front: a workgroup owns BFC columns of the
 // padded front and, for them, clears the column, sets the identity padding of the pivot block, takes the pivot rows of
@@ -908,16 +977,15 @@ void bigfront_assemble_kernel(int s, const int64_t *__restrict__ front_off, cons
 // v = work vector of the front (length h, unpadded local indices) in HBM.
 constexpr int SB = 64;
 
-__global__ __launch_bounds__(FT)
-void front_bwd_kernel(const int32_t *__restrict__ level_fronts, const int64_t *__restrict__ front_off,
-	const int32_t *__restrict__ front_h, const int32_t *__restrict__ front_w, const int32_t *__restrict__ front_ld,
-	const int32_t *__restrict__ front_pad,
-	const int64_t *__restrict__ front_voff, const int32_t *__restrict__ rows_ptr, const int32_t *__restrict__ rows,
-	const double *__restrict__ fronts, double *__restrict__ vbuf, double *__restrict__ xperm)
+__device__ __forceinline__ void front_bwd_body(const int s, const FrontArgs &fa, double *tri, double (*part)[SB])
 {
-	__shared__ double tri[SB * (SB + 1)];
-	__shared__ double part[FT / 64][SB];
-	const int s = level_fronts[blockIdx.x];
+	const int64_t *__restrict__ front_off = fa.front_off;
+	const int32_t *__restrict__ front_h = fa.front_h, *__restrict__ front_w = fa.front_w, *__restrict__ front_ld = fa.front_ld;
+	const int32_t *__restrict__ front_pad = fa.front_pad;
+	const int64_t *__restrict__ front_voff = fa.front_voff;
+	const int32_t *__restrict__ rows_ptr = fa.rows_ptr, *__restrict__ rows = fa.rows;
+	const double *fronts = fa.fronts;
+	double *vbuf = fa.vbuf, *xperm = fa.xperm;
 	const int h = front_h[s], w = front_w[s], ld = front_ld[s], pad = front_pad[s];
 	const double *F = fronts + front_off[s];
 	double *v = vbuf + front_voff[s];
@@ -985,6 +1053,116 @@ void front_bwd_kernel(const int32_t *__restrict__ level_fronts, const int64_t *_
 		xperm[rw[c]] = v[c];
 }
 
+__global__ __launch_bounds__(FT)
+void front_bwd_kernel(const int32_t *__restrict__ level_fronts, FrontArgs fa)
+{
+	__shared__ double tri[SB * (SB + 1)];
+	__shared__ double part[FT / 64][SB];
+	front_bwd_body(level_fronts[blockIdx.x], fa, tri, part);
+}
+
+// --------------------------------------------------------------------------------------------------
+// Dependency-driven launches. Level by level the factorization of a pose graph is 13-21 levels x up to three size
+// classes = 30-60 launches of 13-17 us each, every one as long as its slowest front and separated by a launch
+// boundary, plus one launch per level for the backward substitution. Here ONE launch covers all those levels: a
+// workgroup per front, enumerated children first (level order), which waits for its children's flags in device
+// memory (their update matrices are extend-added by the parent), runs the class's kernel body and publishes its own
+// flag behind an agent-scope release. A front starts the moment its own children are done; the critical path is the
+// heaviest root-to-leaf chain of fronts, not the sum over the levels of the slowest front of each.
+// Progress: workgroups are dispatched in block order, so every producer a resident workgroup waits for is resident or
+// finished. Every wait is bounded all the same (wall clock -> abort word -> every later wait falls through -> the host
+// reports the failure and goes back to the level-by-level launches).
+// Flags hold the epoch of the solve that last finished the front: no clearing between solves.
+// --------------------------------------------------------------------------------------------------
+struct DagArgs {
+	const int32_t *list;      // fronts in dispatch order
+	const int32_t *front_cls; // size class per front
+	const int32_t *front_parent, *front_level;
+	int *done;                // [ns] epoch of the last completed factorization / substitution of the front
+	int epoch;
+	int level_limit;          // fronts of levels >= level_limit are handled by launches of their own (no flags)
+	int *abort;
+	long long timeout_ticks;
+};
+
+__device__ __forceinline__ bool dag_wait(const int *flag, int value, int *abort, long long timeout_ticks)
+{
+	const long long t0 = wall_clock64();
+	for(int it = 0; __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != value; ++ it) {
+		if((it & 15) == 15) {
+			if(__hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+				return false;
+			if(wall_clock64() - t0 > timeout_ticks) {
+				__hip_atomic_store(abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				return false;
+			}
+		}
+		__builtin_amdgcn_s_sleep(1);
+	}
+	return true;
+}
+
+// the workgroup's stores are complete and visible device-wide, then the flag
+__device__ __forceinline__ void dag_publish(int *flag, int value)
+{
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+	if(threadIdx.x == 0) {
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+}
+
+constexpr int DAG_THREADS = 1024;
+
+__global__ __launch_bounds__(DAG_THREADS)
+void front_dag_kernel(DagArgs da, FrontArgs fa)
+{
+	extern __shared__ double fsm[];
+	const int s = da.list[blockIdx.x];
+	const int cls = da.front_cls[s];
+	const int nth = cls == 0 ? 64 : (cls == 1 ? 256 : (cls == 2 ? 512 : 1024));
+	const int tid = threadIdx.x;
+	if(tid >= nth)
+		return; // (a barrier does not wait for waves that have ended)
+	if(tid == 0) {
+		for(int cq = fa.child_ptr[s]; cq < fa.child_ptr[s + 1]; ++ cq)
+			if(!dag_wait(da.done + fa.child_list[cq], da.epoch, da.abort, da.timeout_ticks))
+				break; // aborted: the front is computed from garbage and discarded by the host
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	}
+	__syncthreads();
+	if(cls == 0)
+		front_body<32, 64, false>(s, fa, fsm);
+	else if(cls == 1)
+		front_body<64, 256, false>(s, fa, fsm);
+	else if(cls == 2)
+		front_body<128, 512, false>(s, fa, fsm);
+	else
+		front_body<MID_FRONT_MAX, 1024, true>(s, fa, fsm);
+	dag_publish(da.done + s, da.epoch);
+}
+
+__global__ __launch_bounds__(FT)
+void front_bwd_dag_kernel(DagArgs da, FrontArgs fa)
+{
+	__shared__ double tri[SB * (SB + 1)];
+	__shared__ double part[FT / 64][SB];
+	const int s = da.list[blockIdx.x];
+	if(threadIdx.x == 0) {
+		const int p = da.front_parent[s];
+		if(p >= 0 && da.front_level[p] < da.level_limit) // (ancestors above the limit were finished by earlier launches)
+			dag_wait(da.done + p, da.epoch, da.abort, da.timeout_ticks);
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	}
+	__syncthreads();
+	front_bwd_body(s, fa, tri, part);
+	dag_publish(da.done + s, da.epoch);
+}
+
 __global__ void gather_perm_kernel(int64_t n, const int32_t *__restrict__ perm, const double *__restrict__ src,
 	double *__restrict__ dst)
 {
@@ -1001,6 +1179,23 @@ __global__ void scatter_perm_kernel(int64_t n, const int32_t *__restrict__ perm,
 		dst[perm[i]] = src[i];
 }
 
+static FrontArgs make_front_args(spp_ctx *ctx, SparsePlan *sp, const double *d_vals)
+{
+	FrontArgs fa;
+	fa.front_off = sp->front_off.p;
+	fa.front_h = sp->front_h.p; fa.front_w = sp->front_w.p; fa.front_ld = sp->front_ld.p; fa.front_pad = sp->front_pad.p;
+	fa.asm_ptr = sp->asm_ptr.p; fa.asm_src = sp->asm_src.p; fa.asm_dst = sp->asm_dst.p; fa.asm_shape = sp->asm_shape.p;
+	fa.child_ptr = sp->child_ptr.p; fa.child_list = sp->child_list.p; fa.rel_ptr = sp->rel_ptr.p; fa.rel = sp->rel.p;
+	fa.rows_ptr = sp->rows_ptr.p; fa.rows = sp->rows.p;
+	fa.front_voff = sp->front_voff.p;
+	fa.xperm = sp->xperm.p;
+	fa.vals = d_vals;
+	fa.fronts = sp->fronts.p;
+	fa.vbuf = sp->vbuf.p;
+	fa.info = ctx->dense.info.p;
+	return fa;
+}
+
 template <int HP, int NTH, bool GMEM>
 static void launch_front_lds(spp_ctx *ctx, SparsePlan *sp, int32_t b, int32_t e, const double *d_vals)
 {
@@ -1014,9 +1209,7 @@ static void launch_front_lds(spp_ctx *ctx, SparsePlan *sp, int32_t b, int32_t e,
 		attr = true;
 	}
 	hipLaunchKernelGGL((front_lds_kernel<HP, NTH, GMEM>), dim3((unsigned)(e - b)), dim3(NTH), lds, ctx->stream,
-		sp->level_fronts.p + b, sp->front_off.p, sp->front_h.p, sp->front_w.p, sp->front_ld.p, sp->front_pad.p,
-		sp->asm_ptr.p, sp->asm_src.p, sp->asm_dst.p, sp->asm_shape.p, sp->child_ptr.p, sp->child_list.p,
-		sp->rel_ptr.p, sp->rel.p, sp->rows_ptr.p, sp->rows.p, sp->xperm.p, d_vals, sp->fronts.p, ctx->dense.info.p);
+		sp->level_fronts.p + b, make_front_args(ctx, sp, d_vals));
 }
 
 static void sparse_enqueue(spp_ctx *ctx, const double *d_vals, double *d_rhs);
@@ -1081,7 +1274,39 @@ static void sparse_enqueue(spp_ctx *ctx, const double *d_vals, double *d_rhs)
 	phase_begin(ctx, SPP_PHASE_FACTOR);
 	// P b: every front takes its pivot rows of it as its right-hand-side column
 	hipLaunchKernelGGL(gather_perm_kernel, dim3(gn), dim3(256), 0, s, sp->n, sp->perm_scalar.p, d_rhs, sp->xperm.p);
-	for(int64_t l = 0; l < sp->n_levels; ++ l) {
+	static int use_dag = -1;
+	if(use_dag < 0) {
+		const char *e = getenv("SPP_SPARSE_DAG"); // 0: one launch per level and size class (round 1 / 2 schedule)
+		use_dag = e ? atoi(e) : 1;
+		if(const char *g = getenv("SPP_SPARSE_GRAPH")) // (a captured graph would replay a stale epoch)
+			if(atoi(g))
+				use_dag = 0;
+	}
+	const bool dag = use_dag && sp->dag_ok && sp->dag_n > 0;
+	const int32_t first_level = dag ? sp->dag_level_limit : 0;
+	DagArgs da;
+	da.front_cls = sp->front_cls.p;
+	da.front_parent = sp->front_parent.p;
+	da.front_level = sp->front_level.p;
+	da.done = sp->dag_done.p;
+	da.level_limit = sp->dag_level_limit;
+	da.abort = ctx->dense.info.p + 3;
+	da.timeout_ticks = (long long)(500.0 * 1e5); // 500 ms of the 100 MHz wall clock
+	da.epoch = 0;
+	da.list = nullptr;
+	if(dag) {
+		static bool attr = false;
+		if(!attr) {
+			SPP_HIP_CHECK(hipFuncSetAttribute((const void*)front_dag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+				(int)((std::max<size_t>((size_t)17 * MID_FRONT_MAX + MID_FRONT_MAX, (size_t)128 * 129 + 128) + 2 * 16 * PT + 8) * sizeof(double))));
+			attr = true;
+		}
+		da.epoch = ++ sp->dag_epoch;
+		da.list = sp->dag_list.p;
+		hipLaunchKernelGGL(front_dag_kernel, dim3((unsigned)sp->dag_n), dim3(DAG_THREADS), sp->dag_lds, s, da,
+			make_front_args(ctx, sp, d_vals));
+	}
+	for(int64_t l = first_level; l < sp->n_levels; ++ l) {
 		const int32_t *cp = sp->h_cls_ptr.data() + l * NCLS;
 		launch_front_lds<32, 64, false>(ctx, sp, cp[0], cp[1], d_vals);
 		launch_front_lds<64, 256, false>(ctx, sp, cp[1], cp[2], d_vals);
@@ -1108,12 +1333,16 @@ static void sparse_enqueue(spp_ctx *ctx, const double *d_vals, double *d_rhs)
 	SPP_HIP_CHECK(hipGetLastError());
 	phase_begin(ctx, SPP_PHASE_TRISOLVE);
 	// the forward substitution R^T y = P b was carried by the factorization (slot column of every front): backward only
-	for(int64_t l = sp->n_levels; l > 0;) {
+	for(int64_t l = sp->n_levels; l > first_level;) {
 		-- l;
 		const int32_t b = sp->h_level_ptr[l], e = sp->h_level_ptr[l + 1];
 		hipLaunchKernelGGL(front_bwd_kernel, dim3((unsigned)(e - b)), dim3(FT), 0, s,
-			sp->level_fronts.p + b, sp->front_off.p, sp->front_h.p, sp->front_w.p, sp->front_ld.p, sp->front_pad.p,
-			sp->front_voff.p, sp->rows_ptr.p, sp->rows.p, sp->fronts.p, sp->vbuf.p, sp->xperm.p);
+			sp->level_fronts.p + b, make_front_args(ctx, sp, d_vals));
+	}
+	if(dag) { // the levels below: one launch, a front waits for its parent
+		da.epoch = ++ sp->dag_epoch;
+		da.list = sp->dag_list_bwd.p;
+		hipLaunchKernelGGL(front_bwd_dag_kernel, dim3((unsigned)sp->dag_n), dim3(FT), 0, s, da, make_front_args(ctx, sp, d_vals));
 	}
 	hipLaunchKernelGGL(scatter_perm_kernel, dim3(gn), dim3(256), 0, s, sp->n, sp->perm_scalar.p, sp->xperm.p, d_rhs);
 	phase_end(ctx, SPP_PHASE_TRISOLVE);
