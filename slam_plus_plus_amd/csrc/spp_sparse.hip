@@ -82,6 +82,7 @@ struct SparsePlan {
 	DevBuf<int32_t> dag_list, dag_list_bwd;    // dispatch order of the factorization / of the backward substitution
 	DevBuf<int> dag_done;                      // [ns] epoch flags
 	int32_t dag_n = 0, dag_level_limit = 0;
+	int32_t dag_first1 = 0;                    // position in dag_list of the first front of level 1
 	int dag_epoch = 0;
 	size_t dag_lds = 0;                        // dynamic LDS of the factorization launch (largest class present)
 	bool dag_ok = true;                        // false after a timed-out wait: level-by-level launches from then on
@@ -491,6 +492,9 @@ void sparse_analyze(spp_ctx *ctx, const Structure &st)
 		std::stable_sort(dag_list.begin(), dag_list.end(), [&](int32_t a, int32_t b) {
 			return level[a] != level[b] ? level[a] < level[b] : front_cls[a] > front_cls[b]; });
 		dag_list_bwd.assign(dag_list.rbegin(), dag_list.rend()); // parents first
+		sp->dag_first1 = 0;
+		while(sp->dag_first1 < (int32_t)dag_list.size() && level[dag_list[sp->dag_first1]] == 0)
+			++ sp->dag_first1;
 		sp->dag_n = (int32_t)dag_list.size();
 		const size_t hp = max_cls == 0 ? 32 : (max_cls == 1 ? 64 : (max_cls == 2 ? 128 : MID_FRONT_MAX));
 		sp->dag_lds = ((max_cls == 3 ? std::max<size_t>((size_t)17 * MID_FRONT_MAX + MID_FRONT_MAX, (size_t)128 * 129 + 128) : hp * (hp + 1) + hp)
@@ -668,8 +672,12 @@ struct FrontArgs {
 	int *info;
 };
 
-template <int HP, int NTH, bool GMEM>
-__device__ __forceinline__ void front_body(const int s, const FrontArgs &fa, double *fsm)
+struct NoWait { __device__ __forceinline__ void operator()() const { } };
+
+// `wait_children` is called (by every thread) once the parts of the assembly that do not depend on the children --
+// clearing, identity padding, the blocks of Lambda, the right-hand side -- are done, right before the extend-add
+template <int HP, int NTH, bool GMEM, class WaitFn>
+__device__ __forceinline__ void front_body(const int s, const FrontArgs &fa, double *fsm, const WaitFn &wait_children)
 {
 	const int64_t *__restrict__ front_off = fa.front_off;
 	const int32_t *__restrict__ front_h = fa.front_h, *__restrict__ front_w = fa.front_w, *__restrict__ front_ld = fa.front_ld;
@@ -730,6 +738,7 @@ __device__ __forceinline__ void front_body(const int s, const FrontArgs &fa, dou
 		for(int r = tid; r < w; r += NTH)
 			T[r + (int64_t)cs * TSF] = xperm[rw[r]];
 	}
+	wait_children();
 	__syncthreads();
 	// ---- extend-add of the children's update matrices (their right-hand-side column included), children in list order
 	for(int cq = child_ptr[s]; cq < child_ptr[s + 1]; ++ cq) {
@@ -879,7 +888,7 @@ __global__ __launch_bounds__(NTH)
 void front_lds_kernel(const int32_t *__restrict__ list, FrontArgs fa)
 {
 	extern __shared__ double fsm[];
-	front_body<HP, NTH, GMEM>(list[blockIdx.x], fa, fsm);
+	front_body<HP, NTH, GMEM>(list[blockIdx.x], fa, fsm, NoWait());
 }
 
 // ---- big fronts (image does not fit LDS): assembled in HBM in the padded layout, factored by the
@@ -977,7 +986,13 @@ void bigfront_assemble_kernel(int s, const int64_t *__restrict__ front_off, cons
 // v = work vector of the front (length h, unpadded local indices) in HBM.
 constexpr int SB = 64;
 
-__device__ __forceinline__ void front_bwd_body(const int s, const FrontArgs &fa, double *tri, double (*part)[SB])
+constexpr int BWD_VL = 1024; // fronts up to this height keep their work vector in LDS
+
+// `wait_parent` is called (by every thread) once what does not depend on the ancestors -- y on the pivot rows, the
+// triangle of the first block -- has been fetched
+template <class WaitFn>
+__device__ __forceinline__ void front_bwd_body(const int s, const FrontArgs &fa, double *tri, double (*part)[SB], double *vl,
+	const WaitFn &wait_parent)
 {
 	const int64_t *__restrict__ front_off = fa.front_off;
 	const int32_t *__restrict__ front_h = fa.front_h, *__restrict__ front_w = fa.front_w, *__restrict__ front_ld = fa.front_ld;
@@ -988,20 +1003,11 @@ __device__ __forceinline__ void front_bwd_body(const int s, const FrontArgs &fa,
 	double *vbuf = fa.vbuf, *xperm = fa.xperm;
 	const int h = front_h[s], w = front_w[s], ld = front_ld[s], pad = front_pad[s];
 	const double *F = fronts + front_off[s];
-	double *v = vbuf + front_voff[s];
+	double *v = (h <= BWD_VL) ? vl : vbuf + front_voff[s];
 	const int32_t *rw = rows + rows_ptr[s];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	// own part: y = the slot column of the factored front (the forward substitution happened inside the factorization);
-	// beyond: final x of the ancestors; the slot itself takes no part (0)
-	{
-		const int cs = padded(h - 1, w, pad);
-		for(int c = tid; c < h; c += FT)
-			v[c] = (c < w) ? F[c + (int64_t)cs * ld] : ((c < h - 1) ? xperm[rw[c]] : 0.0);
-	}
-	__syncthreads();
 	const int nblk = (w + SB - 1) / SB;
-	for(int bk = nblk; bk > 0;) {
-		-- bk;
+	auto load_tri = [&](int bk) {
 		const int j0 = bk * SB;
 		const int nbk = (w - j0 < SB) ? (w - j0) : SB;
 		for(int e = tid; e < nbk * nbk; e += FT) {
@@ -1009,6 +1015,26 @@ __device__ __forceinline__ void front_bwd_body(const int s, const FrontArgs &fa,
 			if(i <= k)
 				tri[i + k * (SB + 1)] = F[(j0 + i) + (int64_t)(j0 + k) * ld];
 		}
+	};
+	// own part: y = the slot column of the factored front (the forward substitution happened inside the factorization)
+	{
+		const int cs = padded(h - 1, w, pad);
+		for(int c = tid; c < w; c += FT)
+			v[c] = F[c + (int64_t)cs * ld];
+	}
+	if(nblk > 0)
+		load_tri(nblk - 1);
+	wait_parent();
+	// beyond: final x of the ancestors; the slot itself takes no part (0)
+	for(int c = w + tid; c < h; c += FT)
+		v[c] = (c < h - 1) ? xperm[rw[c]] : 0.0;
+	__syncthreads();
+	for(int bk = nblk; bk > 0;) {
+		-- bk;
+		const int j0 = bk * SB;
+		const int nbk = (w - j0 < SB) ? (w - j0) : SB;
+		if(bk != nblk - 1)
+			load_tri(bk);
 		// lane = row j0 + lane of the block; the waves split the columns after the block
 		{
 			double acc[4] = {0, 0, 0, 0};
@@ -1058,7 +1084,8 @@ void front_bwd_kernel(const int32_t *__restrict__ level_fronts, FrontArgs fa)
 {
 	__shared__ double tri[SB * (SB + 1)];
 	__shared__ double part[FT / 64][SB];
-	front_bwd_body(level_fronts[blockIdx.x], fa, tri, part);
+	__shared__ double vl[BWD_VL];
+	front_bwd_body(level_fronts[blockIdx.x], fa, tri, part, vl, NoWait());
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -1081,6 +1108,7 @@ struct DagArgs {
 	int *done;                // [ns] epoch of the last completed factorization / substitution of the front
 	int epoch;
 	int level_limit;          // fronts of levels >= level_limit are handled by launches of their own (no flags)
+	int level_first;          // factorization: the fronts of levels < level_first were finished by earlier launches
 	int *abort;
 	long long timeout_ticks;
 };
@@ -1126,22 +1154,26 @@ void front_dag_kernel(DagArgs da, FrontArgs fa)
 	const int tid = threadIdx.x;
 	if(tid >= nth)
 		return; // (a barrier does not wait for waves that have ended)
-	if(tid == 0) {
-		for(int cq = fa.child_ptr[s]; cq < fa.child_ptr[s + 1]; ++ cq)
-			if(!dag_wait(da.done + fa.child_list[cq], da.epoch, da.abort, da.timeout_ticks))
-				break; // aborted: the front is computed from garbage and discarded by the host
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-	}
-	__syncthreads();
+	// the children's flags are awaited inside the body, after the part of the assembly that does not need them
+	auto wait_children = [&]() {
+		if(tid == 0) {
+			for(int cq = fa.child_ptr[s]; cq < fa.child_ptr[s + 1]; ++ cq) {
+				const int c = fa.child_list[cq];
+				if(da.front_level[c] >= da.level_first && !dag_wait(da.done + c, da.epoch, da.abort, da.timeout_ticks))
+					break; // aborted: the front is computed from garbage and discarded by the host
+			}
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		}
+	};
 	if(cls == 0)
-		front_body<32, 64, false>(s, fa, fsm);
+		front_body<32, 64, false>(s, fa, fsm, wait_children);
 	else if(cls == 1)
-		front_body<64, 256, false>(s, fa, fsm);
+		front_body<64, 256, false>(s, fa, fsm, wait_children);
 	else if(cls == 2)
-		front_body<128, 512, false>(s, fa, fsm);
+		front_body<128, 512, false>(s, fa, fsm, wait_children);
 	else
-		front_body<MID_FRONT_MAX, 1024, true>(s, fa, fsm);
+		front_body<MID_FRONT_MAX, 1024, true>(s, fa, fsm, wait_children);
 	dag_publish(da.done + s, da.epoch);
 }
 
@@ -1150,16 +1182,19 @@ void front_bwd_dag_kernel(DagArgs da, FrontArgs fa)
 {
 	__shared__ double tri[SB * (SB + 1)];
 	__shared__ double part[FT / 64][SB];
+	__shared__ double vl[BWD_VL];
 	const int s = da.list[blockIdx.x];
-	if(threadIdx.x == 0) {
-		const int p = da.front_parent[s];
-		if(p >= 0 && da.front_level[p] < da.level_limit) // (ancestors above the limit were finished by earlier launches)
-			dag_wait(da.done + p, da.epoch, da.abort, da.timeout_ticks);
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-	}
-	__syncthreads();
-	front_bwd_body(s, fa, tri, part);
+	auto wait_parent = [&]() {
+		if(threadIdx.x == 0) {
+			const int p = da.front_parent[s];
+			if(p >= 0 && da.front_level[p] < da.level_limit) // (ancestors above the limit were finished by earlier launches)
+				dag_wait(da.done + p, da.epoch, da.abort, da.timeout_ticks);
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		}
+		__syncthreads();
+	};
+	front_bwd_body(s, fa, tri, part, vl, wait_parent);
 	dag_publish(da.done + s, da.epoch);
 }
 
@@ -1293,6 +1328,7 @@ static void sparse_enqueue(spp_ctx *ctx, const double *d_vals, double *d_rhs)
 	da.abort = ctx->dense.info.p + 3;
 	da.timeout_ticks = (long long)(500.0 * 1e5); // 500 ms of the 100 MHz wall clock
 	da.epoch = 0;
+	da.level_first = 0;
 	da.list = nullptr;
 	if(dag) {
 		static bool attr = false;
@@ -1302,9 +1338,13 @@ static void sparse_enqueue(spp_ctx *ctx, const double *d_vals, double *d_rhs)
 			attr = true;
 		}
 		da.epoch = ++ sp->dag_epoch;
-		da.list = sp->dag_list.p;
-		hipLaunchKernelGGL(front_dag_kernel, dim3((unsigned)sp->dag_n), dim3(DAG_THREADS), sp->dag_lds, s, da,
-			make_front_args(ctx, sp, d_vals));
+		// (the leaves as plain launches of their own size class in front of this one -- the dependency-driven launch reserves
+		// the LDS of the largest class for every workgroup -- measured no gain on either pose graph: dropped)
+		const int32_t skip = 0;
+		da.list = sp->dag_list.p + skip;
+		if(sp->dag_n > skip)
+			hipLaunchKernelGGL(front_dag_kernel, dim3((unsigned)(sp->dag_n - skip)), dim3(DAG_THREADS), sp->dag_lds, s, da,
+				make_front_args(ctx, sp, d_vals));
 	}
 	for(int64_t l = first_level; l < sp->n_levels; ++ l) {
 		const int32_t *cp = sp->h_cls_ptr.data() + l * NCLS;
