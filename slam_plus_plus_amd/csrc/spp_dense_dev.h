@@ -1,0 +1,435 @@
+// spp_dense_dev.h -- device-side building blocks of the dense factor that more than one translation unit uses:
+// the fully staged MFMA tile product (row-panel solve / trailing update of the chain kernels) and the factorization of
+// one 128 x 128 diagonal block in LDS. spp_dense.hip launches them as kernels of their own and inside its fused chain
+// kernel; spp_sparse.hip runs them inside the dependency-driven frontal kernel (teams of workgroups on the big fronts).
+#pragma once
+#include "spp_internal.h"
+#include "spp_tiles.h"
+
+namespace spp {
+
+// Fully staged variant for the latency-critical chain kernels (row-panel solve and tile-row update):
+// K <= 128, both operand panels are loaded into LDS ONCE (all global loads in flight together, one
+// barrier), then the MFMAs run without further synchronization. LDS row stride K_MAX + 2 doubles:
+// conflict-free ds_read_b64 fragments (lanes l & 15 step 4 banks, lanes l >> 4 step 2 banks).
+constexpr int FS_KMAX = 128, FS_STRIDE = FS_KMAX + 2;
+
+// one BM x BN tile of C at (m0, n0) by the first (BM / WM) * (BN / WN) waves of the workgroup (the body shared by
+// gemm_tn_staged_kernel and the fused update + diagonal-block kernel); fs_lds: (BM + BN) * FS_STRIDE doubles
+// SC1: the C tile is stored with agent-scope atomic (write-through) stores -- for a tile that another workgroup of the
+// SAME launch reads with agent-scope atomic loads after a counter hand-off (no release / acquire fences, see
+// update_potrf_kernel)
+template <int BM, int BN, int WM, int WN, int MODE, int ATRI, int SC1 = 0>
+__device__ __forceinline__ void gemm_tn_staged_tile(const int64_t m0, const int64_t n0, int64_t M, int64_t N,
+	const double *__restrict__ A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, double *fs_lds)
+{
+	constexpr bool a_upper_tri = ATRI != 0; // A(k, m) = 0 for k > m, BM covers all of A's columns (m0 == 0)
+	constexpr int NWM = BM / WM, NWN = BN / WN, NT = NWM * NWN * 64;
+	constexpr int TA = WM / 16, TB = WN / 16;
+	double *As = fs_lds, *Bs = fs_lds + BM * FS_STRIDE;
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int wm = (wave % NWM) * WM, wn = (wave / NWM) * WN;
+	const int l15 = lane & 15, l4 = lane >> 4;
+	// stage A (BM columns) and B (BN columns): piece p -> (column p / 64, piece p % 64); K == FS_KMAX.
+	// All loads of a thread are issued before its first LDS store (one exposed memory round trip).
+	constexpr int KP = FS_KMAX / 2, PA = (BM * KP) / NT, PB = (BN * KP) / NT;
+	static_assert((BM * KP) % NT == 0 && (BN * KP) % NT == 0, "staging must divide evenly");
+	{
+		double2 va[PA], vb[PB];
+#pragma unroll
+		for(int i = 0; i < PA; ++ i) {
+			const int p = tid + i * NT, col = p / KP, q = p % KP;
+			int64_t gc = m0 + col;
+			if(gc > M - 1) gc = M - 1;
+			// a_upper_tri: A(k, m) = 0 for k > m (the inverse of a diagonal block): the zero half is not fetched
+			va[i] = (a_upper_tri && 2 * q > gc) ? make_double2(0, 0) : *(const double2*)(A + gc * lda + 2 * q);
+		}
+#pragma unroll
+		for(int i = 0; i < PB; ++ i) {
+			const int p = tid + i * NT, col = p / KP, q = p % KP;
+			int64_t gc = n0 + col;
+			if(gc > N - 1) gc = N - 1;
+			vb[i] = *(const double2*)(B + gc * ldb + 2 * q);
+		}
+#pragma unroll
+		for(int i = 0; i < PA; ++ i) {
+			const int p = tid + i * NT, col = p / KP, q = p % KP;
+			*(double2*)(&As[col * FS_STRIDE + 2 * q]) = va[i];
+		}
+#pragma unroll
+		for(int i = 0; i < PB; ++ i) {
+			const int p = tid + i * NT, col = p / KP, q = p % KP;
+			*(double2*)(&Bs[col * FS_STRIDE + 2 * q]) = vb[i];
+		}
+	}
+	v4f64 acc[TB][TA];
+#pragma unroll
+	for(int b = 0; b < TB; ++ b)
+#pragma unroll
+		for(int a = 0; a < TA; ++ a) {
+			acc[b][a] = (v4f64){0, 0, 0, 0};
+			if(MODE == 0) {
+				const int64_t m = m0 + wm + a * 16 + l15;
+#pragma unroll
+				for(int r = 0; r < 4; ++ r) {
+					const int64_t n = n0 + wn + b * 16 + l4 + 4 * r;
+					if(m < M && n < N)
+						acc[b][a][r] = -C[m + n * ldc];
+				}
+			}
+		}
+	__syncthreads();
+	// rows wm .. wm + WM - 1 of an upper triangular A^T only see k < wm + WM (wave-uniform bound)
+	const int kend = (a_upper_tri && wm + WM < FS_KMAX) ? wm + WM : FS_KMAX; // compile-time FS_KMAX unless ATRI
+#pragma unroll 4
+	for(int k4 = 0; k4 < kend; k4 += 4) {
+		double fa[TA], fb[TB];
+#pragma unroll
+		for(int a = 0; a < TA; ++ a)
+			fa[a] = As[(wm + a * 16 + l15) * FS_STRIDE + k4 + l4];
+#pragma unroll
+		for(int b = 0; b < TB; ++ b)
+			fb[b] = Bs[(wn + b * 16 + l15) * FS_STRIDE + k4 + l4];
+#pragma unroll
+		for(int b = 0; b < TB; ++ b)
+#pragma unroll
+			for(int a = 0; a < TA; ++ a)
+				acc[b][a] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[b], fa[a], acc[b][a], 0, 0, 0);
+	}
+#pragma unroll
+	for(int b = 0; b < TB; ++ b)
+#pragma unroll
+		for(int a = 0; a < TA; ++ a) {
+			const int64_t m = m0 + wm + a * 16 + l15;
+#pragma unroll
+			for(int r = 0; r < 4; ++ r) {
+				const int64_t n = n0 + wn + b * 16 + l4 + 4 * r;
+				if(m < M && n < N) {
+					const double val = (MODE == 0) ? -acc[b][a][r] : acc[b][a][r];
+					if(SC1)
+						__hip_atomic_store(&C[m + n * ldc], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					else
+						C[m + n * ldc] = val;
+				}
+			}
+		}
+}
+
+// --------------------------------------------------------------------------------------------------
+// potrf of one 128 x 128 diagonal block, entirely in LDS, blocked by 16 with MFMA f64 updates.
+//   in : T = upper triangle of the block (global, column-major, ld); padding rows/cols (>= n_valid)
+//        are exact identity; if has_rhs, column n_valid holds a right-hand side (rows < n_valid)
+//   out: upper triangle <- R_kk ; rhs column <- R_kk^-T rhs ;
+//        tinv (128 x 128 column-major, dense upper triangular) <- R_kk^-1
+// Per 16-wide panel J (16 waves):
+//   B  row panel: X = Dinv^T Y for the tiles right of the diagonal (R part) and left of it (G part:
+//      the rows of (R^-1)^T accumulated in the unused LOWER triangle of the block); one tile per wave
+//   C  trailing update T[I,K] -= P_I^T P_K (R part), G[I,Cb] -= P_I^T G[J,Cb] (G part): waves 1..15
+//      take the tiles two at a time (independent MFMA chains); wave 0 updates the NEXT diagonal tile
+//      first and then
+//   A  factors and inverts that 16 x 16 tile in registers (square-root-free elimination, 5 double
+//      shuffles per pivot) while the other waves finish C -- the serial part hides under the update.
+// 2 workgroup barriers per panel. Dinv / G_JJ scratch tiles are double buffered (panel parity).
+// info[0] = first failing global pivot index + 1 (non-positive pivot, Eigen's LLT test).
+// --------------------------------------------------------------------------------------------------
+#ifdef SPP_POTRF_TRACE
+__device__ long long spp_potrf_trace[64]; // cycle stamps of thread 0 / thread 64 (tools/potrf_trace.hip)
+#define SPP_STAMP(slot, who) do { if(tid == (who)) spp_potrf_trace[slot] = (long long)__builtin_readcyclecounter(); } while(0)
+#else
+#define SPP_STAMP(slot, who) do { } while(0)
+#endif
+
+constexpr int NB = DENSE_NB;
+#ifndef SPP_POTRF_TS
+#define SPP_POTRF_TS (NB + 1)
+#endif
+constexpr int TS = SPP_POTRF_TS;   // LDS column stride of the block image: element (r, c) at r + c * TS
+constexpr int POTRF_THREADS = 1024;
+constexpr int POTRF_LDS_DOUBLES = NB * TS + 4 * 16 * PT + 2 * NB + 8;
+
+// workgroup barrier that orders LDS accesses only (s_waitcnt lgkmcnt(0) + s_barrier): unlike __syncthreads()
+// it does not wait for outstanding global stores
+__device__ __forceinline__ void lds_barrier()
+{
+	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// COH: the block was written by other workgroups of the same launch with write-through stores: read it with
+// agent-scope atomic (sc1) loads -- they bypass this CU's L1, which a plain load could be served from stale
+template <bool COH>
+__device__ __forceinline__ double2 ld_blk2(const double *p)
+{
+	if(COH) {
+		double2 v;
+		v.x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		v.y = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		return v;
+	}
+	return *(const double2*)p;
+}
+
+template <bool COH = false>
+__device__ __forceinline__ void potrf_diag_body(double *__restrict__ Ablk, int64_t ld, int n_valid, int has_rhs,
+	double *__restrict__ tinv, int *__restrict__ info, int64_t k0, double *sm)
+{
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	SPP_STAMP(0, 0);
+	double *T = sm;                  // NB x NB image, stride TS
+	double *DvB = T + NB * TS;       // 2 x Dinv[k][i] at Dv[k + i * PT] (upper triangular, zeros below)
+	double *GdB = DvB + 2 * 16 * PT; // 2 x G_JJ[r][c] = Dinv[c][r] at Gd[r + c * PT] (lower triangular incl. diagonal)
+	double *dinv = GdB + 2 * 16 * PT; // 1 / R[j][j]
+	double *yv = dinv + NB;          // carried right-hand side
+	int *fail = (int*)(yv + NB);
+	const int l15 = lane & 15, l4 = lane >> 4;
+	constexpr int NW = POTRF_THREADS / 64;
+	const int rhs_col = (has_rhs && n_valid < NB) ? n_valid : -1;
+	// Prologue. The first diagonal tile only needs its own 16 x 16 entries: wave 0 fetches them and starts
+	// the elimination (5 500 cycles) while the other 15 waves stream in the rest of the block (6 500 cycles).
+	// Not possible when the carried right-hand side sits inside that tile (n_valid < 16): plain order then.
+	const bool fast0 = !(rhs_col >= 0 && rhs_col < 16);
+	if(tid == 0)
+		*fail = 0;
+	if(fast0) {
+		if(wave == 0) {
+			double v[4];
+#pragma unroll
+			for(int t = 0; t < 4; ++ t)
+				v[t] = COH ? __hip_atomic_load(&Ablk[l15 + (int64_t)(l4 + 4 * t) * ld], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+				           : Ablk[l15 + (int64_t)(l4 + 4 * t) * ld];
+#pragma unroll
+			for(int t = 0; t < 4; ++ t)
+				T[l15 + (l4 + 4 * t) * TS] = v[t];
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			diag_tile_factor<TS>(T, DvB, GdB, dinv, 0, lane, fail, info, k0);
+		} else {
+			// 16-byte pieces of the block without its first tile, spread over the 960 threads of waves 1..15;
+			// all of a thread's loads are in flight before its first LDS store
+			constexpr int NP = NB * NB / 2, NTH = POTRF_THREADS - 64, NIT = (NP + NTH - 1) / NTH;
+			double2 v[NIT];
+#pragma unroll
+			for(int t = 0; t < NIT; ++ t) {
+				const int e = (tid - 64) + t * NTH, r = (e & (NB / 2 - 1)) * 2, c = e >> 6;
+				// only the upper triangle is an input (16 x 16 tiles on or above the diagonal): the tiles below it
+				// are first ASSIGNED by the G part of the update, never read before -- 44 % of the block not fetched
+				if(e < NP && !(r < 16 && c < 16) && (r >> 4) <= (c >> 4))
+					v[t] = ld_blk2<COH>(Ablk + r + (int64_t)c * ld);
+			}
+#pragma unroll
+			for(int t = 0; t < NIT; ++ t) {
+				const int e = (tid - 64) + t * NTH, r = (e & (NB / 2 - 1)) * 2, c = e >> 6;
+				if(e < NP && !(r < 16 && c < 16) && (r >> 4) <= (c >> 4)) {
+					T[r + c * TS] = v[t].x;
+					T[r + 1 + c * TS] = v[t].y;
+				}
+			}
+		}
+		__syncthreads();
+		SPP_STAMP(1, 0);
+		if(tid < NB) {
+			yv[tid] = (rhs_col >= 0 && tid < n_valid) ? T[tid + rhs_col * TS] : 0.0;
+			if(tid >= 16)
+				dinv[tid] = 1.0; // entries 0..15 were set by the elimination of the first tile
+		}
+		__syncthreads();
+		if(rhs_col >= 0 && tid < NB)
+			T[tid + rhs_col * TS] = (tid == rhs_col) ? 1.0 : 0.0; // the rhs column becomes plain padding
+		__syncthreads();
+	} else {
+		{
+			double2 v[NB * NB / 2 / POTRF_THREADS];
+#pragma unroll
+			for(int t = 0; t < NB * NB / 2 / POTRF_THREADS; ++ t) {
+				const int e = tid + t * POTRF_THREADS, r = (e & (NB / 2 - 1)) * 2, c = e >> 6;
+				v[t] = ld_blk2<COH>(Ablk + r + (int64_t)c * ld);
+			}
+#pragma unroll
+			for(int t = 0; t < NB * NB / 2 / POTRF_THREADS; ++ t) {
+				const int e = tid + t * POTRF_THREADS, r = (e & (NB / 2 - 1)) * 2, c = e >> 6;
+				T[r + c * TS] = v[t].x;
+				T[r + 1 + c * TS] = v[t].y;
+			}
+		}
+		__syncthreads();
+		SPP_STAMP(1, 0);
+		if(tid < NB) {
+			yv[tid] = (rhs_col >= 0 && tid < n_valid) ? T[tid + rhs_col * TS] : 0.0;
+			dinv[tid] = 1.0;
+		}
+		__syncthreads();
+		if(rhs_col >= 0 && tid < NB)
+			T[tid + rhs_col * TS] = (tid == rhs_col) ? 1.0 : 0.0; // the rhs column becomes plain padding
+		__syncthreads();
+		if(wave == 0)
+			diag_tile_factor<TS>(T, DvB, GdB, dinv, 0, lane, fail, info, k0);
+		__syncthreads();
+	}
+	SPP_STAMP(2, 0);
+
+	for(int J = 0; J < NB / 16; ++ J) {
+		if(*fail)
+			return;
+		SPP_STAMP(3 + 6 * J, 0);
+		const int j0 = J * 16;
+		if(j0 >= n_valid) {
+			// a panel of padding only (exact identity rows / columns, nothing right of them in these rows): its rows of R and
+			// its columns of the inverse are unit vectors; nothing to eliminate, no LDS traffic, no barrier (uniform branch)
+			const int nv16 = (n_valid + 15) & ~15;
+			for(int e = tid; e < 16 * (NB - j0); e += POTRF_THREADS) {
+				const int r = j0 + (e & 15), c = j0 + (e >> 4);
+				if(r <= c && c != rhs_col)
+					Ablk[r + (int64_t)c * ld] = (r == c) ? 1.0 : 0.0;
+			}
+			for(int e = tid; e < 16 * NB; e += POTRF_THREADS) {
+				const int r = e & (NB - 1), c = j0 + (e >> 7);
+				tinv[r + c * NB] = (r == c) ? 1.0 : ((r < c && r < nv16) ? T[c + r * TS] : 0.0); // G[c][r] of the valid rows: zeros, assigned there
+			}
+			continue;
+		}
+		const double *Dv = DvB + (J & 1) * 16 * PT, *Gd = GdB + (J & 1) * 16 * PT;
+		// ---- B: row panel. tiles t < J: G part (columns 16 t ..), tiles t >= J: R part (columns 16 (t + 1) ..)
+		if(wave < 7) {
+			const int ct = (wave < J) ? wave : wave + 1;
+			double *Y = T + j0 + (ct * 16) * TS;
+			const v4f64 x = tile_atb(Dv, 1, PT, Y, 1, TS, lane); // X[i][j] = sum_k Dinv[k][i] Y[k][j]
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+#pragma unroll
+			for(int r = 0; r < 4; ++ r)
+				Y[(l4 + 4 * r) + l15 * TS] = x[r];
+		} else if(wave == 7 && lane < 16) { // the carried right-hand side, y_J = Dinv^T y_J
+			double s = 0;
+			for(int k = 0; k < 16; ++ k)
+				s += Dv[k + lane * PT] * yv[j0 + k];
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			yv[j0 + lane] = s;
+		}
+		SPP_STAMP(4 + 6 * J, 0);
+		lds_barrier(); // LDS traffic only: the write-back stores stay in flight
+		SPP_STAMP(5 + 6 * J, 0);
+		SPP_STAMP(6 + 6 * J, 64);
+		// ---- C (+ A of the next panel on wave 0): trailing update with the panel rows P = T[j0 .. j0 + 16, :]
+		{
+			const int nI = NB / 16 - 1 - J;         // row tiles I = J + 1 .. 7
+			const int nR = nI * (nI + 1) / 2;       // R part: I <= K
+			const int nG = nI * (J + 1);            // G part: Cb = 0 .. J
+			// tile q -> (I, Ct, gpart); q = 0 is the next diagonal tile (I = K = J + 1)
+			auto decode = [&](int q, int &I, int &Ct, bool &gpart) {
+				gpart = q >= nR;
+				if(!gpart) {
+					int a = 0, rem = q;
+					while(rem >= nI - a) {
+						rem -= nI - a;
+						++ a;
+					}
+					I = J + 1 + a;
+					Ct = I + rem;
+				} else {
+					const int g = q - nR;
+					I = J + 1 + g / (J + 1);
+					Ct = g % (J + 1);
+				}
+			};
+			if(wave == 0) {
+				if(nI > 0 && j0 + 16 < n_valid) { // (a next tile of padding only is not factored: its panel is skipped)
+					const double *Pa = T + j0 + ((J + 1) * 16) * TS;
+					const v4f64 d = tile_atb(Pa, 1, TS, Pa, 1, TS, lane);
+					double *D = T + ((J + 1) * 16) + ((J + 1) * 16) * TS;
+#pragma unroll
+					for(int r = 0; r < 4; ++ r)
+						D[(l4 + 4 * r) + l15 * TS] -= d[r];
+					__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+					__builtin_amdgcn_wave_barrier();
+					diag_tile_factor<TS>(T, DvB + ((J + 1) & 1) * 16 * PT, GdB + ((J + 1) & 1) * 16 * PT, dinv,
+						j0 + 16, lane, fail, info, k0);
+				}
+			} else {
+				// The waves that share wave 0's SIMD (4, 8, 12) stay out of the trailing update: the dependent MFMA
+				// chain of the diagonal tile then has its matrix core to itself (7 000 -> 5 300 cycles per panel).
+				// Row block J -- final since step B -- goes back to global memory inside this phase (below): R (rows
+				// j0 .. j0+15 right of and on the diagonal) and columns j0 .. j0+15 of the inverse.
+				constexpr int NCW = NW - 1 - (NW / 4 - 1);
+				const int slot = wave - 1 - (wave >> 2);
+				for(int q = ((wave & 3) ? slot + 1 : (1 << 20)); q < nR + nG; q += 2 * NCW) { // two tiles per wave and round
+					const int q1 = q + NCW;
+					int I0, C0, I1 = 0, C1 = 0;
+					bool g0, g1 = false;
+					decode(q, I0, C0, g0);
+					const bool have1 = q1 < nR + nG;
+					if(have1)
+						decode(q1, I1, C1, g1);
+					const double *a0 = T + j0 + (I0 * 16) * TS;
+					const bool gd0 = g0 && C0 == J;
+					const double *b0 = gd0 ? Gd : T + j0 + (C0 * 16) * TS;
+					if(have1) {
+						const double *a1 = T + j0 + (I1 * 16) * TS;
+						const bool gd1 = g1 && C1 == J;
+						const double *b1 = gd1 ? Gd : T + j0 + (C1 * 16) * TS;
+						v4f64 d0, d1;
+						tile_atb2<TS>(a0, b0, 1, gd0 ? PT : TS, a1, b1, 1, gd1 ? PT : TS, lane, d0, d1);
+						double *D0 = T + (I0 * 16) + (C0 * 16) * TS, *D1 = T + (I1 * 16) + (C1 * 16) * TS;
+#pragma unroll
+						for(int r = 0; r < 4; ++ r) {
+							double *dp = D0 + (l4 + 4 * r) + l15 * TS;
+							*dp = gd0 ? -d0[r] : *dp - d0[r]; // first touch of a G tile: assign
+							double *dq = D1 + (l4 + 4 * r) + l15 * TS;
+							*dq = gd1 ? -d1[r] : *dq - d1[r];
+						}
+					} else {
+						const v4f64 d0 = tile_atb(a0, 1, TS, b0, 1, gd0 ? PT : TS, lane);
+						double *D0 = T + (I0 * 16) + (C0 * 16) * TS;
+#pragma unroll
+						for(int r = 0; r < 4; ++ r) {
+							double *dp = D0 + (l4 + 4 * r) + l15 * TS;
+							*dp = gd0 ? -d0[r] : *dp - d0[r];
+						}
+					}
+				}
+				// write-back of row block J by all of waves 1..15, after their tiles (the stores stay in flight across
+				// the barriers below). Measured alternatives: waves 4 / 8 / 12 alone doing it (they have no tiles) took
+				// longer than wave 0's elimination and slowed it through the shared SIMD; three tiles per wave and round
+				// cost what two rounds of two cost (the update is bound by the MFMA pipe: one v_mfma_f64_16x16x4 per
+				// ~105 cycles and SIMD, which is also what bounds the bare-MFMA loop at 47 TFLOP/s).
+				{
+					const int t15 = (wave - 1) * 64 + lane; // 0 .. 959
+					for(int e = t15; e < 16 * (NB - j0); e += (NW - 1) * 64) { // R: 16 rows x (NB - j0) columns
+						const int r = j0 + (e & 15), c = j0 + (e >> 4);
+						if(r <= c && c != rhs_col)
+							Ablk[r + (int64_t)c * ld] = T[r + c * TS];
+					}
+					for(int e = t15; e < 16 * NB; e += (NW - 1) * 64) { // inverse: columns j0 .. j0+15, all 128 rows
+						const int r = e & (NB - 1), c = j0 + (e >> 7);
+						double v = 0;
+						if(r == c)
+							v = dinv[r];
+						else if(r < c)
+							v = T[c + r * TS]; // G[c][r]
+						tinv[r + c * NB] = v;
+					}
+				}
+				// rhs: y_i -= sum_k P[k][i] y_J[k], by the threads of waves 8..9
+				const int ti = tid - 512;
+				if(ti >= j0 + 16 && ti < NB) {
+					double s = 0;
+					for(int k = 0; k < 16; ++ k)
+						s += T[(j0 + k) + ti * TS] * yv[j0 + k];
+					yv[ti] -= s;
+				}
+			}
+		}
+		SPP_STAMP(7 + 6 * J, 0);
+		SPP_STAMP(8 + 6 * J, 64);
+		lds_barrier(); // LDS traffic only: the write-back stores stay in flight
+	}
+	SPP_STAMP(51, 0);
+	if(*fail)
+		return;
+	// R and the inverse went back block row by block row inside the loop; the carried rhs remains
+	if(rhs_col >= 0 && tid < n_valid)
+		Ablk[tid + (int64_t)rhs_col * ld] = yv[tid];
+	SPP_STAMP(52, 0);
+}
+
+
+} // namespace spp

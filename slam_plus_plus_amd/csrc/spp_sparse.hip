@@ -990,7 +990,8 @@ constexpr int BWD_VL = 1024; // fronts up to this height keep their work vector 
 
 // `wait_parent` is called (by every thread) once what does not depend on the ancestors -- y on the pivot rows, the
 // triangle of the first block -- has been fetched
-template <class WaitFn>
+// NT threads; a wave takes U columns of the part right of a block per round (U loads in flight per lane)
+template <int NT, int U, class WaitFn>
 __device__ __forceinline__ void front_bwd_body(const int s, const FrontArgs &fa, double *tri, double (*part)[SB], double *vl,
 	const WaitFn &wait_parent)
 {
@@ -1010,7 +1011,7 @@ __device__ __forceinline__ void front_bwd_body(const int s, const FrontArgs &fa,
 	auto load_tri = [&](int bk) {
 		const int j0 = bk * SB;
 		const int nbk = (w - j0 < SB) ? (w - j0) : SB;
-		for(int e = tid; e < nbk * nbk; e += FT) {
+		for(int e = tid; e < nbk * nbk; e += NT) {
 			const int i = e % nbk, k = e / nbk;
 			if(i <= k)
 				tri[i + k * (SB + 1)] = F[(j0 + i) + (int64_t)(j0 + k) * ld];
@@ -1019,14 +1020,14 @@ __device__ __forceinline__ void front_bwd_body(const int s, const FrontArgs &fa,
 	// own part: y = the slot column of the factored front (the forward substitution happened inside the factorization)
 	{
 		const int cs = padded(h - 1, w, pad);
-		for(int c = tid; c < w; c += FT)
+		for(int c = tid; c < w; c += NT)
 			v[c] = F[c + (int64_t)cs * ld];
 	}
 	if(nblk > 0)
 		load_tri(nblk - 1);
 	wait_parent();
 	// beyond: final x of the ancestors; the slot itself takes no part (0)
-	for(int c = w + tid; c < h; c += FT)
+	for(int c = w + tid; c < h; c += NT)
 		v[c] = (c < h - 1) ? xperm[rw[c]] : 0.0;
 	__syncthreads();
 	for(int bk = nblk; bk > 0;) {
@@ -1037,19 +1038,30 @@ __device__ __forceinline__ void front_bwd_body(const int s, const FrontArgs &fa,
 			load_tri(bk);
 		// lane = row j0 + lane of the block; the waves split the columns after the block
 		{
-			double acc[4] = {0, 0, 0, 0};
-			const double *rowp = F + j0 + lane;
-			int c = j0 + nbk + wave * 4;
-			if(lane < nbk) {
-				for(; c + 4 <= h; c += 4 * (FT / 64)) {
+			double acc[U];
 #pragma unroll
-					for(int u = 0; u < 4; ++ u)
-						acc[u] += rowp[(int64_t)padded(c + u, w, pad) * ld] * v[c + u];
+			for(int u = 0; u < U; ++ u)
+				acc[u] = 0;
+			const double *rowp = F + j0 + lane;
+			int c = j0 + nbk + wave * U;
+			if(lane < nbk) {
+				for(; c + U <= h; c += U * (NT / 64)) {
+					double f[U];
+#pragma unroll
+					for(int u = 0; u < U; ++ u)
+						f[u] = rowp[(int64_t)padded(c + u, w, pad) * ld];
+#pragma unroll
+					for(int u = 0; u < U; ++ u)
+						acc[u] += f[u] * v[c + u];
 				}
-				for(int u = 0; u < 4 && c + u < h; ++ u) // ragged last group (belongs to exactly one wave)
+				for(int u = 0; u < U && c + u < h; ++ u) // ragged last group (belongs to exactly one wave)
 					acc[0] += rowp[(int64_t)padded(c + u, w, pad) * ld] * v[c + u];
 			}
-			part[wave][lane] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+			double sum = 0;
+#pragma unroll
+			for(int u = 0; u < U; u += 4)
+				sum += (acc[u] + acc[u + 1]) + (acc[u + 2] + acc[u + 3]);
+			part[wave][lane] = sum;
 		}
 		__syncthreads();
 		if(wave == 0) {
@@ -1057,7 +1069,7 @@ __device__ __forceinline__ void front_bwd_body(const int s, const FrontArgs &fa,
 			if(lane < nbk) {
 				t = v[j0 + lane];
 #pragma unroll
-				for(int q = 0; q < FT / 64; ++ q)
+				for(int q = 0; q < NT / 64; ++ q)
 					t -= part[q][lane];
 			}
 			const double rinv = (lane < nbk) ? 1.0 / tri[lane + lane * (SB + 1)] : 0.0;
@@ -1075,17 +1087,18 @@ __device__ __forceinline__ void front_bwd_body(const int s, const FrontArgs &fa,
 		}
 		__syncthreads();
 	}
-	for(int c = tid; c < w; c += FT)
+	for(int c = tid; c < w; c += NT)
 		xperm[rw[c]] = v[c];
 }
 
-__global__ __launch_bounds__(FT)
+template <int NT, int U>
+__global__ __launch_bounds__(NT)
 void front_bwd_kernel(const int32_t *__restrict__ level_fronts, FrontArgs fa)
 {
 	__shared__ double tri[SB * (SB + 1)];
-	__shared__ double part[FT / 64][SB];
+	__shared__ double part[NT / 64][SB];
 	__shared__ double vl[BWD_VL];
-	front_bwd_body(level_fronts[blockIdx.x], fa, tri, part, vl, NoWait());
+	front_bwd_body<NT, U>(level_fronts[blockIdx.x], fa, tri, part, vl, NoWait());
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -1194,7 +1207,7 @@ void front_bwd_dag_kernel(DagArgs da, FrontArgs fa)
 		}
 		__syncthreads();
 	};
-	front_bwd_body(s, fa, tri, part, vl, wait_parent);
+	front_bwd_body<FT, 4>(s, fa, tri, part, vl, wait_parent);
 	dag_publish(da.done + s, da.epoch);
 }
 
@@ -1376,8 +1389,13 @@ static void sparse_enqueue(spp_ctx *ctx, const double *d_vals, double *d_rhs)
 	for(int64_t l = sp->n_levels; l > first_level;) {
 		-- l;
 		const int32_t b = sp->h_level_ptr[l], e = sp->h_level_ptr[l + 1];
-		hipLaunchKernelGGL(front_bwd_kernel, dim3((unsigned)(e - b)), dim3(FT), 0, s,
-			sp->level_fronts.p + b, make_front_args(ctx, sp, d_vals));
+		// the levels up here hold the wide fronts (hundreds of columns right of a block): 16 waves, 8 loads in flight each
+		if(l >= sp->dag_level_limit)
+			hipLaunchKernelGGL((front_bwd_kernel<1024, 8>), dim3((unsigned)(e - b)), dim3(1024), 0, s,
+				sp->level_fronts.p + b, make_front_args(ctx, sp, d_vals));
+		else
+			hipLaunchKernelGGL((front_bwd_kernel<FT, 4>), dim3((unsigned)(e - b)), dim3(FT), 0, s,
+				sp->level_fronts.p + b, make_front_args(ctx, sp, d_vals));
 	}
 	if(dag) { // the levels below: one launch, a front waits for its parent
 		da.epoch = ++ sp->dag_epoch;

@@ -3,7 +3,9 @@ import csv, glob, sys
 path = glob.glob(sys.argv[1] + "/**/*_kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(path)))
 ks = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r["Queue_Id"]) for r in rows)
-idx = [i for i, k in enumerate(ks) if "cinv_kernel" in k[2]]
+import os
+anchor = os.environ.get("TL_ANCHOR", "cinv_kernel")
+idx = [i for i, k in enumerate(ks) if anchor in k[2]]
 i0 = idx[int(sys.argv[2]) if len(sys.argv) > 2 else -2]
 t0 = ks[i0][0]
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 60
