@@ -19,7 +19,10 @@ constexpr int FS_KMAX = 128, FS_STRIDE = FS_KMAX + 2;
 // SC1: the C tile is stored with agent-scope atomic (write-through) stores -- for a tile that another workgroup of the
 // SAME launch reads with agent-scope atomic loads after a counter hand-off (no release / acquire fences, see
 // update_potrf_kernel)
-template <int BM, int BN, int WM, int WN, int MODE, int ATRI, int SC1 = 0>
+// PART (= threads of the workgroup, or 0): the workgroup has MORE waves than the tile uses and keeps them (a persistent
+// workgroup that goes on to other work): ALL of its threads stage the operands -- half the staging registers per
+// thread, twice the loads in flight --, the waves beyond the first (BM / WM) * (BN / WN) skip the MFMAs
+template <int BM, int BN, int WM, int WN, int MODE, int ATRI, int SC1 = 0, int PART = 0>
 __device__ __forceinline__ void gemm_tn_staged_tile(const int64_t m0, const int64_t n0, int64_t M, int64_t N,
 	const double *__restrict__ A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, double *fs_lds)
 {
@@ -32,13 +35,15 @@ __device__ __forceinline__ void gemm_tn_staged_tile(const int64_t m0, const int6
 	const int l15 = lane & 15, l4 = lane >> 4;
 	// stage A (BM columns) and B (BN columns): piece p -> (column p / 64, piece p % 64); K == FS_KMAX.
 	// All loads of a thread are issued before its first LDS store (one exposed memory round trip).
-	constexpr int KP = FS_KMAX / 2, PA = (BM * KP) / NT, PB = (BN * KP) / NT;
-	static_assert((BM * KP) % NT == 0 && (BN * KP) % NT == 0, "staging must divide evenly");
+	constexpr int NTS = PART ? PART : NT; // threads that stage
+	constexpr int KP = FS_KMAX / 2, PA = (BM * KP) / NTS, PB = (BN * KP) / NTS;
+	static_assert((BM * KP) % NTS == 0 && (BN * KP) % NTS == 0, "staging must divide evenly");
+	const bool live = !PART || tid < NT;
 	{
 		double2 va[PA], vb[PB];
 #pragma unroll
 		for(int i = 0; i < PA; ++ i) {
-			const int p = tid + i * NT, col = p / KP, q = p % KP;
+			const int p = tid + i * NTS, col = p / KP, q = p % KP;
 			int64_t gc = m0 + col;
 			if(gc > M - 1) gc = M - 1;
 			// a_upper_tri: A(k, m) = 0 for k > m (the inverse of a diagonal block): the zero half is not fetched
@@ -46,19 +51,19 @@ __device__ __forceinline__ void gemm_tn_staged_tile(const int64_t m0, const int6
 		}
 #pragma unroll
 		for(int i = 0; i < PB; ++ i) {
-			const int p = tid + i * NT, col = p / KP, q = p % KP;
+			const int p = tid + i * NTS, col = p / KP, q = p % KP;
 			int64_t gc = n0 + col;
 			if(gc > N - 1) gc = N - 1;
 			vb[i] = *(const double2*)(B + gc * ldb + 2 * q);
 		}
 #pragma unroll
 		for(int i = 0; i < PA; ++ i) {
-			const int p = tid + i * NT, col = p / KP, q = p % KP;
+			const int p = tid + i * NTS, col = p / KP, q = p % KP;
 			*(double2*)(&As[col * FS_STRIDE + 2 * q]) = va[i];
 		}
 #pragma unroll
 		for(int i = 0; i < PB; ++ i) {
-			const int p = tid + i * NT, col = p / KP, q = p % KP;
+			const int p = tid + i * NTS, col = p / KP, q = p % KP;
 			*(double2*)(&Bs[col * FS_STRIDE + 2 * q]) = vb[i];
 		}
 	}
@@ -68,7 +73,7 @@ __device__ __forceinline__ void gemm_tn_staged_tile(const int64_t m0, const int6
 #pragma unroll
 		for(int a = 0; a < TA; ++ a) {
 			acc[b][a] = (v4f64){0, 0, 0, 0};
-			if(MODE == 0) {
+			if(MODE == 0 && live) {
 				const int64_t m = m0 + wm + a * 16 + l15;
 #pragma unroll
 				for(int r = 0; r < 4; ++ r) {
@@ -79,6 +84,8 @@ __device__ __forceinline__ void gemm_tn_staged_tile(const int64_t m0, const int6
 			}
 		}
 	__syncthreads();
+	if(!live)
+		return;
 	// rows wm .. wm + WM - 1 of an upper triangular A^T only see k < wm + WM (wave-uniform bound)
 	const int kend = (a_upper_tri && wm + WM < FS_KMAX) ? wm + WM : FS_KMAX; // compile-time FS_KMAX unless ATRI
 #pragma unroll 4

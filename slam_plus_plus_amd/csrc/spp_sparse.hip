@@ -26,6 +26,7 @@
 
 #include "spp_internal.h"
 #include "spp_tiles.h"
+#include "spp_dense_dev.h"
 #include <algorithm>
 #include <numeric>
 #include <stdio.h>
@@ -81,7 +82,12 @@ struct SparsePlan {
 	DevBuf<int32_t> front_cls, front_parent, front_level; // [ns]
 	DevBuf<int32_t> dag_list, dag_list_bwd;    // dispatch order of the factorization / of the backward substitution
 	DevBuf<int> dag_done;                      // [ns] epoch flags
-	int32_t dag_n = 0, dag_level_limit = 0;
+	int32_t dag_n = 0, dag_n_bwd = 0, dag_level_limit = 0;
+	int dag_solves = 0;                        // factorizations run on the team barrier counters so far
+	DevBuf<int32_t> dag_rank, front_team;      // per block of the factorization launch / per front
+	DevBuf<int> team_bar;                      // [ns] barrier counters of the teams (monotonic)
+	DevBuf<int64_t> front_tinv;                // [ns] offset of a big front's diagonal-block inverses
+	DevBuf<double> team_tinv;
 	int32_t dag_first1 = 0;                    // position in dag_list of the first front of level 1
 	int dag_epoch = 0;
 	size_t dag_lds = 0;                        // dynamic LDS of the factorization launch (largest class present)
@@ -189,6 +195,9 @@ int64_t sparse_info(const spp_ctx *ctx, int what)
 }
 
 static const int NCLS = 5;
+// big fronts inside the dependency-driven launch (bigfront_team_body): threads and LDS of a team member
+constexpr int TEAM_THREADS = 1024;
+constexpr size_t TEAM_LDS_DOUBLES = (size_t)(NB + 16) * FS_STRIDE > (size_t)POTRF_LDS_DOUBLES ? (size_t)(NB + 16) * FS_STRIDE : (size_t)POTRF_LDS_DOUBLES;
 static const int MID_FRONT_MAX = 640; // largest padded height the one-workgroup in-place (HBM image) kernel is built for
 static const int MID_FRONT_DEFAULT = 320; // default split: fronts above go to the dense MFMA kernels
 
@@ -474,31 +483,62 @@ void sparse_analyze(spp_ctx *ctx, const Structure &st)
 				max_steps = std::max<int64_t>(max_steps, (front_w[q] + front_pad[q]) / DENSE_NB);
 		dense_reserve(ctx, max_steps);
 	}
-	// dependency-driven part: every level below the first one that holds a big (multi-kernel) front
-	std::vector<int32_t> dag_list, dag_list_bwd;
+	// dependency-driven part: every level below the first one that holds a big front the launch cannot take; with teams
+	// (SPP_SPARSE_TEAMS, default on) it takes the big fronts as well -- G consecutive workgroups each -- and covers the
+	// whole tree
+	std::vector<int32_t> dag_list, dag_list_bwd, dag_rank, front_team(ns, 1);
+	std::vector<int64_t> front_tinv(ns, 0);
+	int64_t tinv_doubles = 0;
 	{
+		bool teams = true;
+		if(const char *e = getenv("SPP_SPARSE_TEAMS"))
+			teams = atoi(e) != 0;
 		int32_t limit = (int32_t)sp->n_levels;
-		for(int64_t q = 0; q < ns; ++ q)
-			if(front_cls[q] == 4)
-				limit = std::min(limit, level[q]);
+		if(!teams)
+			for(int64_t q = 0; q < ns; ++ q)
+				if(front_cls[q] == 4)
+					limit = std::min(limit, level[q]);
 		sp->dag_level_limit = limit;
 		int max_cls = 0;
+		std::vector<int32_t> fronts_in;
 		for(int64_t q = 0; q < ns; ++ q)
 			if(level[q] < limit) {
-				dag_list.push_back((int32_t)q);
+				fronts_in.push_back((int32_t)q);
 				max_cls = std::max(max_cls, front_cls[q]);
 			}
 		// children first; inside a level the long fronts (large classes) first
-		std::stable_sort(dag_list.begin(), dag_list.end(), [&](int32_t a, int32_t b) {
+		std::stable_sort(fronts_in.begin(), fronts_in.end(), [&](int32_t a, int32_t b) {
 			return level[a] != level[b] ? level[a] < level[b] : front_cls[a] > front_cls[b]; });
-		dag_list_bwd.assign(dag_list.rbegin(), dag_list.rend()); // parents first
+		dag_list_bwd.assign(fronts_in.rbegin(), fronts_in.rend()); // parents first
+		int team_max = 12;
+		if(const char *e = getenv("SPP_SPARSE_TEAM_MAX"))
+			team_max = std::max(1, std::min(64, atoi(e)));
+		for(size_t i = 0; i < fronts_in.size(); ++ i) {
+			const int32_t q = fronts_in[i];
+			int G = 1;
+			if(front_cls[q] == 4) {
+				const int32_t hp = front_h[q] + front_pad[q];
+				G = std::max(2, std::min(team_max, (hp + 63) / 64)); // about one workgroup per 64 columns of the padded front
+				front_team[q] = G;
+				front_tinv[q] = tinv_doubles;
+				tinv_doubles += (int64_t)((front_w[q] + front_pad[q]) / DENSE_NB) * DENSE_NB * DENSE_NB;
+			}
+			for(int r = 0; r < G; ++ r) {
+				dag_list.push_back(q);
+				dag_rank.push_back(r);
+			}
+		}
 		sp->dag_first1 = 0;
 		while(sp->dag_first1 < (int32_t)dag_list.size() && level[dag_list[sp->dag_first1]] == 0)
 			++ sp->dag_first1;
 		sp->dag_n = (int32_t)dag_list.size();
+		sp->dag_n_bwd = (int32_t)dag_list_bwd.size();
 		const size_t hp = max_cls == 0 ? 32 : (max_cls == 1 ? 64 : (max_cls == 2 ? 128 : MID_FRONT_MAX));
-		sp->dag_lds = ((max_cls == 3 ? std::max<size_t>((size_t)17 * MID_FRONT_MAX + MID_FRONT_MAX, (size_t)128 * 129 + 128) : hp * (hp + 1) + hp)
-			+ 2 * 16 * PT + 8) * sizeof(double);
+		size_t lds_doubles = (max_cls >= 3 ? std::max<size_t>((size_t)17 * MID_FRONT_MAX + MID_FRONT_MAX, (size_t)128 * 129 + 128) : hp * (hp + 1) + hp)
+			+ 2 * 16 * PT + 8;
+		if(max_cls == 4)
+			lds_doubles = std::max(lds_doubles, TEAM_LDS_DOUBLES);
+		sp->dag_lds = lds_doubles * sizeof(double);
 	}
 	sp->h_front_ld = front_ld;
 	sp->h_front_pad = front_pad;
@@ -635,6 +675,13 @@ void sparse_analyze(spp_ctx *ctx, const Structure &st)
 	sp->front_level.upload(level, s);
 	sp->dag_list.upload(dag_list, s);
 	sp->dag_list_bwd.upload(dag_list_bwd, s);
+	sp->dag_rank.upload(dag_rank, s);
+	sp->front_team.upload(front_team, s);
+	sp->front_tinv.upload(front_tinv, s);
+	sp->team_tinv.reserve((size_t)std::max<int64_t>(tinv_doubles, 1));
+	sp->team_bar.reserve((size_t)std::max<int64_t>(ns, 1));
+	SPP_HIP_CHECK(hipMemsetAsync(sp->team_bar.p, 0, (size_t)std::max<int64_t>(ns, 1) * sizeof(int), s));
+	sp->dag_solves = 0;
 	sp->dag_done.reserve((size_t)std::max<int64_t>(ns, 1));
 	SPP_HIP_CHECK(hipMemsetAsync(sp->dag_done.p, 0, (size_t)std::max<int64_t>(ns, 1) * sizeof(int), s));
 	sp->dag_epoch = 0;
@@ -1124,6 +1171,13 @@ struct DagArgs {
 	int level_first;          // factorization: the fronts of levels < level_first were finished by earlier launches
 	int *abort;
 	long long timeout_ticks;
+	// big fronts: a team of workgroups each (consecutive blocks)
+	const int32_t *rank;       // per block: rank inside its front's team
+	const int32_t *front_team; // per front: team size (1: a single workgroup)
+	int *team_bar;             // per front: monotonic barrier counter
+	const int64_t *front_tinv; // per front: offset of its diagonal-block inverses in tinv
+	double *tinv;
+	int solve_index;           // number of factorizations run on these counters before this one
 };
 
 __device__ __forceinline__ bool dag_wait(const int *flag, int value, int *abort, long long timeout_ticks)
@@ -1155,6 +1209,172 @@ __device__ __forceinline__ void dag_publish(int *flag, int value)
 	}
 }
 
+// ---- big fronts inside the dependency-driven launch: a TEAM of workgroups per front -------------------------------
+// Host-driven, a big front (image in HBM, pivot block padded to a multiple of 128) cost a launch for its assembly and
+// three to five per 128 pivots, one front after the other (sphere2500: twelve of them, 0.95 of 1.5 ms). Here G
+// consecutive workgroups of the launch share the front: each assembles a contiguous range of columns (the children
+// in list order: deterministic), then per 128 pivots rank 0 factors the diagonal block in LDS (potrf_diag_body), all
+// solve the row panel in 16-column slabs and update the trailing part in 64 x 64 blocks (the staged MFMA tile
+// products of the dense factor), with a barrier of the team -- a monotonic counter in device memory behind an
+// agent-scope release, an acquire behind the wait -- between the phases. Fronts of one level run side by side, the
+// part of the assembly that needs no child runs ahead of the wait for the children.
+__device__ __forceinline__ void team_barrier(int *counter, int target, int *abort, long long timeout_ticks)
+{
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+	if(threadIdx.x == 0) {
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const long long t0 = wall_clock64();
+		for(int it = 0; __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target < 0; ++ it) {
+			if((it & 15) == 15) {
+				if(__hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+					break;
+				if(wall_clock64() - t0 > timeout_ticks) {
+					__hip_atomic_store(abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					break;
+				}
+			}
+			__builtin_amdgcn_s_sleep(1);
+		}
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	}
+	__syncthreads();
+}
+
+
+// the three heavy phases as functions of their own: inlined into the team body their register pressure adds to the
+// state the body keeps across them and the allocator (128 VGPRs at 1024 threads) spills inside the hot loops
+__device__ __noinline__ void team_potrf(double *Ablk, int64_t ld, int n_valid, double *tv, int *info, int64_t k0, double *sm)
+{
+	potrf_diag_body<false>(Ablk, ld, n_valid, 0, tv, info, k0, sm);
+}
+
+__device__ __noinline__ void team_panel_tile(int64_t n0, int64_t nright, const double *tv, double *P, int64_t ld, double *sm)
+{
+	gemm_tn_staged_tile<NB, 16, 16, 16, 1, 0, 0, TEAM_THREADS>(0, n0, NB, nright, tv, NB, P, ld, P, ld, sm);
+}
+
+__device__ __noinline__ void team_update_tile(int64_t m0, int64_t n0, int64_t nright, const double *P, int64_t ld, double *C, double *sm)
+{
+	gemm_tn_staged_tile<64, 64, 16, 16, 0, 0>(m0, n0, nright, nright, P, ld, P, ld, C, ld, sm);
+}
+
+template <class WaitFn>
+__device__ __forceinline__ void bigfront_team_body(const int s, const int rank, const int G, const FrontArgs &fa,
+	int *bar, const int bar_base, double *tinv, int *abort, long long timeout_ticks, double *sm, const WaitFn &wait_children)
+{
+	__shared__ int jrange[2];
+	const int h = fa.front_h[s], w = fa.front_w[s], ld = fa.front_ld[s], pad = fa.front_pad[s];
+	const int hp = h + pad;
+	double *F = fa.fronts + fa.front_off[s];
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	// ---- assembly of the columns [c0, c1) of the padded front
+	const int per = (((hp + G - 1) / G) + 7) & ~7;
+	const int c0 = (rank * per < hp) ? rank * per : hp, c1 = (c0 + per < hp) ? c0 + per : hp;
+	for(int64_t e = tid; e < (int64_t)(c1 - c0) * ld; e += TEAM_THREADS)
+		F[(int64_t)c0 * ld + e] = 0.0;
+	__syncthreads();
+	for(int i = c0 + tid; i < c1; i += TEAM_THREADS)
+		if(i >= w && i < w + pad)
+			F[i + (int64_t)i * ld] = 1.0; // identity padding of the pivot block
+	{
+		const int cs = padded(h - 1, w, pad); // the right-hand-side slot
+		if(cs >= c0 && cs < c1) {
+			const int32_t *rw = fa.rows + fa.rows_ptr[s];
+			for(int r = tid; r < w; r += TEAM_THREADS)
+				F[r + (int64_t)cs * ld] = fa.xperm[rw[r]];
+		}
+	}
+	// blocks of Lambda: every workgroup walks the front's list and keeps the elements of its columns
+	for(int q = fa.asm_ptr[s] + wave; q < fa.asm_ptr[s + 1]; q += TEAM_THREADS / 64) {
+		const int64_t so = fa.asm_src[q];
+		const double *src = fa.vals + (so >> 1);
+		const int dr = padded(fa.asm_dst[q] & 0xffff, w, pad), dc = padded(fa.asm_dst[q] >> 16, w, pad);
+		const int nr = fa.asm_shape[q] & 0xff, ncol = fa.asm_shape[q] >> 8;
+		if(dc + ncol <= c0 || dc >= c1)
+			continue; // wave-uniform
+		if(lane < nr * ncol) {
+			const int r = lane % nr, c = lane / nr;
+			if(dc + c >= c0 && dc + c < c1)
+				F[(dr + r) + (int64_t)(dc + c) * ld] = (so & 1) ? src[c + ncol * r] : src[r + nr * c];
+		}
+	}
+	wait_children();
+	__syncthreads();
+	// extend-add, children in list order; a child's rows map to ascending parent indices, so the child columns that
+	// land in [c0, c1) are one contiguous range [ja, jb)
+	for(int cq = fa.child_ptr[s]; cq < fa.child_ptr[s + 1]; ++ cq) {
+		const int c = fa.child_list[cq];
+		const int hc = fa.front_h[c], wc = fa.front_w[c], ldc = fa.front_ld[c], oc = wc + fa.front_pad[c];
+		const double *Fc = fa.fronts + fa.front_off[c];
+		const int32_t *rl = fa.rel + fa.rel_ptr[c];
+		const int m = hc - wc;
+		if(tid == 0) {
+			int lo = 0, hi = m; // first j with padded(rl[j]) >= c0
+			while(lo < hi) {
+				const int mid = (lo + hi) >> 1;
+				if(padded(rl[mid], w, pad) < c0) lo = mid + 1; else hi = mid;
+			}
+			jrange[0] = lo;
+			hi = m; // first j with padded(rl[j]) >= c1
+			while(lo < hi) {
+				const int mid = (lo + hi) >> 1;
+				if(padded(rl[mid], w, pad) < c1) lo = mid + 1; else hi = mid;
+			}
+			jrange[1] = lo;
+		}
+		__syncthreads();
+		const int ja = jrange[0], jb = jrange[1];
+		for(int e = tid; e < (jb - ja) * m; e += TEAM_THREADS) {
+			const int j = ja + e / m, i = e % m;
+			if(i <= j)
+				F[padded(rl[i], w, pad) + (int64_t)padded(rl[j], w, pad) * ld] += Fc[(oc + i) + (int64_t)(oc + j) * ldc];
+		}
+		__syncthreads();
+	}
+	int nbar = 0;
+	team_barrier(bar, bar_base + G * (++ nbar), abort, timeout_ticks);
+	// ---- partial factorization, 128 pivots per step
+	const int nsteps = (w + pad) / NB;
+	for(int j = 0; j < nsteps; ++ j) {
+		const int k0 = j * NB, k1 = k0 + NB;
+		double *tv = tinv + (size_t)j * NB * NB;
+		if(rank == 0) {
+			int n_valid = w - k0;
+			n_valid = n_valid < 0 ? 0 : (n_valid > NB ? NB : n_valid);
+			team_potrf(F + k0 + (int64_t)k0 * ld, ld, n_valid, tv, fa.info, (int64_t)k0, sm);
+		}
+		team_barrier(bar, bar_base + G * (++ nbar), abort, timeout_ticks);
+		const int nright = hp - k1; // columns right of the diagonal block (the slot column included)
+		double *P = F + k0 + (int64_t)k1 * ld;
+		// row panel R_kj = (R_kk^-1)^T F_kj in place, 16 columns per tile (eight waves; the other eight idle)
+		for(int sl = rank; sl * 16 < nright; sl += G) {
+			team_panel_tile((int64_t)sl * 16, nright, tv, P, ld, sm);
+			__syncthreads(); // the LDS panels are staged anew by the next tile
+		}
+		team_barrier(bar, bar_base + G * (++ nbar), abort, timeout_ticks);
+		// trailing update F[k1.., k1..] -= P^T P, upper 64 x 64 blocks
+		{
+			const int nb64 = (nright + 63) >> 6, ntile = nb64 * (nb64 + 1) / 2;
+			double *C = F + k1 + (int64_t)k1 * ld;
+			for(int t = rank; t < ntile; t += G) {
+				int bj = 0, rem = t; // tile t -> (bi <= bj), block columns first
+				while(rem > bj) {
+					rem -= bj + 1;
+					++ bj;
+				}
+				const int bi = rem;
+				team_update_tile((int64_t)bi * 64, (int64_t)bj * 64, nright, P, ld, C, sm);
+				__syncthreads();
+			}
+		}
+		team_barrier(bar, bar_base + G * (++ nbar), abort, timeout_ticks);
+	}
+}
+
 constexpr int DAG_THREADS = 1024;
 
 __global__ __launch_bounds__(DAG_THREADS)
@@ -1167,6 +1387,24 @@ void front_dag_kernel(DagArgs da, FrontArgs fa)
 	const int tid = threadIdx.x;
 	if(tid >= nth)
 		return; // (a barrier does not wait for waves that have ended)
+	if(cls == 4) {
+		const int G = da.front_team[s], rank = da.rank[blockIdx.x];
+		auto wait_kids = [&]() {
+			if(tid == 0) {
+				for(int cq = fa.child_ptr[s]; cq < fa.child_ptr[s + 1]; ++ cq)
+					if(!dag_wait(da.done + fa.child_list[cq], da.epoch, da.abort, da.timeout_ticks))
+						break;
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			}
+		};
+		const int nbar = 1 + 3 * ((fa.front_w[s] + fa.front_pad[s]) / NB);
+		bigfront_team_body(s, rank, G, fa, da.team_bar + s, da.solve_index * G * nbar, da.tinv + da.front_tinv[s], da.abort,
+			da.timeout_ticks, fsm, wait_kids);
+		if(rank == 0) // (every member released its stores in the last barrier of the team)
+			dag_publish(da.done + s, da.epoch);
+		return;
+	}
 	// the children's flags are awaited inside the body, after the part of the assembly that does not need them
 	auto wait_children = [&]() {
 		if(tid == 0) {
@@ -1190,13 +1428,17 @@ void front_dag_kernel(DagArgs da, FrontArgs fa)
 	dag_publish(da.done + s, da.epoch);
 }
 
-__global__ __launch_bounds__(FT)
+__global__ __launch_bounds__(1024)
 void front_bwd_dag_kernel(DagArgs da, FrontArgs fa)
 {
 	__shared__ double tri[SB * (SB + 1)];
-	__shared__ double part[FT / 64][SB];
+	__shared__ double part[1024 / 64][SB];
 	__shared__ double vl[BWD_VL];
 	const int s = da.list[blockIdx.x];
+	// wide fronts (hundreds of columns right of a 64-pivot block): 16 waves, eight loads in flight per lane; the others: 4 waves
+	const bool wide = fa.front_h[s] > 192;
+	if(!wide && threadIdx.x >= FT)
+		return; // (a barrier does not wait for waves that have ended)
 	auto wait_parent = [&]() {
 		if(threadIdx.x == 0) {
 			const int p = da.front_parent[s];
@@ -1207,7 +1449,10 @@ void front_bwd_dag_kernel(DagArgs da, FrontArgs fa)
 		}
 		__syncthreads();
 	};
-	front_bwd_body<FT, 4>(s, fa, tri, part, vl, wait_parent);
+	if(wide)
+		front_bwd_body<1024, 8>(s, fa, tri, part, vl, wait_parent);
+	else
+		front_bwd_body<FT, 4>(s, fa, tri, part, vl, wait_parent);
 	dag_publish(da.done + s, da.epoch);
 }
 
@@ -1343,18 +1588,26 @@ static void sparse_enqueue(spp_ctx *ctx, const double *d_vals, double *d_rhs)
 	da.epoch = 0;
 	da.level_first = 0;
 	da.list = nullptr;
+	da.rank = sp->dag_rank.p;
+	da.front_team = sp->front_team.p;
+	da.team_bar = sp->team_bar.p;
+	da.front_tinv = sp->front_tinv.p;
+	da.tinv = sp->team_tinv.p;
+	da.solve_index = 0;
 	if(dag) {
 		static bool attr = false;
 		if(!attr) {
 			SPP_HIP_CHECK(hipFuncSetAttribute((const void*)front_dag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-				(int)((std::max<size_t>((size_t)17 * MID_FRONT_MAX + MID_FRONT_MAX, (size_t)128 * 129 + 128) + 2 * 16 * PT + 8) * sizeof(double))));
+				(int)(std::max<size_t>(std::max<size_t>((size_t)17 * MID_FRONT_MAX + MID_FRONT_MAX, (size_t)128 * 129 + 128) + 2 * 16 * PT + 8, TEAM_LDS_DOUBLES) * sizeof(double))));
 			attr = true;
 		}
 		da.epoch = ++ sp->dag_epoch;
+		da.solve_index = sp->dag_solves ++;
 		// (the leaves as plain launches of their own size class in front of this one -- the dependency-driven launch reserves
 		// the LDS of the largest class for every workgroup -- measured no gain on either pose graph: dropped)
 		const int32_t skip = 0;
 		da.list = sp->dag_list.p + skip;
+		da.rank = sp->dag_rank.p + skip;
 		if(sp->dag_n > skip)
 			hipLaunchKernelGGL(front_dag_kernel, dim3((unsigned)(sp->dag_n - skip)), dim3(DAG_THREADS), sp->dag_lds, s, da,
 				make_front_args(ctx, sp, d_vals));
@@ -1400,7 +1653,7 @@ static void sparse_enqueue(spp_ctx *ctx, const double *d_vals, double *d_rhs)
 	if(dag) { // the levels below: one launch, a front waits for its parent
 		da.epoch = ++ sp->dag_epoch;
 		da.list = sp->dag_list_bwd.p;
-		hipLaunchKernelGGL(front_bwd_dag_kernel, dim3((unsigned)sp->dag_n), dim3(FT), 0, s, da, make_front_args(ctx, sp, d_vals));
+		hipLaunchKernelGGL(front_bwd_dag_kernel, dim3((unsigned)sp->dag_n_bwd), dim3(1024), 0, s, da, make_front_args(ctx, sp, d_vals));
 	}
 	hipLaunchKernelGGL(scatter_perm_kernel, dim3(gn), dim3(256), 0, s, sp->n, sp->perm_scalar.p, sp->xperm.p, d_rhs);
 	phase_end(ctx, SPP_PHASE_TRISOLVE);
