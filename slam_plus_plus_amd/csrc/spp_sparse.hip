@@ -339,13 +339,32 @@ void sparse_analyze(spp_ctx *ctx, const Structure &st)
 			// rows of s beyond its pivot block are a subset of the parent's rows (incl. its pivot block)
 			const int64_t zeros = ws * (hp - hs_beyond);
 			const int64_t merged_panel = (ws + wp) * (ws + hp);
-			const bool small = (ws + wp) <= 24;
+			static int64_t small_w = -1;
+			static double zero_frac = 0.12;
+			if(small_w < 0) {
+				const char *e = getenv("SPP_AMALG_SMALL"); // merged pivot widths up to this are always accepted
+				small_w = e ? atol(e) : 32;
+				if(const char *z = getenv("SPP_AMALG_ZEROS"))
+					zero_frac = atof(z);
+			}
+			const bool small = (ws + wp) <= small_w;
 			// ALL explicit zeros of the merged supernode count (those bought by earlier merges included):
 			// along a chain -- the elimination tree of a banded system -- the newly added zeros alone
 			// always look small next to the growing panel, and the whole chain would collapse into one
 			// dense front
 			const int64_t ztot = zeros + cur_zeros[s] + cur_zeros[s + 1];
-			if(zeros == 0 || small || (double)ztot <= 0.12 * (double)merged_panel) {
+			// (the looser bound only while the merged front stays small: a front of up to ~100 rows costs its latency, ~13 us,
+			// whatever its size, so fewer levels pay; above that the explicit zeros cost flops on the critical path)
+			static int64_t relax_h = -1;
+			static double zero_frac_small = 0.2;
+			if(relax_h < 0) {
+				const char *e = getenv("SPP_AMALG_RELAX_H");
+				relax_h = e ? atol(e) : 96;
+				if(const char *z = getenv("SPP_AMALG_ZEROS_SMALL"))
+					zero_frac_small = atof(z);
+			}
+			const double zf = (ws + hp <= relax_h) ? std::max(zero_frac, zero_frac_small) : zero_frac;
+			if(zeros == 0 || small || (double)ztot <= zf * (double)merged_panel) {
 				merged_into_next[s] = 1;
 				cur_w[s + 1] = ws + wp; // the merged supernode takes the parent's slot
 				cur_zeros[s + 1] = ztot;
@@ -510,15 +529,17 @@ void sparse_analyze(spp_ctx *ctx, const Structure &st)
 		std::stable_sort(fronts_in.begin(), fronts_in.end(), [&](int32_t a, int32_t b) {
 			return level[a] != level[b] ? level[a] < level[b] : front_cls[a] > front_cls[b]; });
 		dag_list_bwd.assign(fronts_in.rbegin(), fronts_in.rend()); // parents first
-		int team_max = 12;
+		int team_max = 40, team_cols = 16; // measured on sphere2500: 12 / 64 -> 1.55 ms, 24 / 32 -> 1.34, 32 / 16 -> 1.27, 48 / 16 -> 1.26, 64 / 8 -> 1.36
 		if(const char *e = getenv("SPP_SPARSE_TEAM_MAX"))
 			team_max = std::max(1, std::min(64, atoi(e)));
+		if(const char *e = getenv("SPP_SPARSE_TEAM_COLS")) // columns of the padded front per member
+			team_cols = std::max(8, std::min(256, atoi(e)));
 		for(size_t i = 0; i < fronts_in.size(); ++ i) {
 			const int32_t q = fronts_in[i];
 			int G = 1;
 			if(front_cls[q] == 4) {
 				const int32_t hp = front_h[q] + front_pad[q];
-				G = std::max(2, std::min(team_max, (hp + 63) / 64)); // about one workgroup per 64 columns of the padded front
+				G = std::max(2, std::min(team_max, (hp + team_cols - 1) / team_cols)); // about one workgroup per team_cols columns of the padded front
 				front_team[q] = G;
 				front_tinv[q] = tinv_doubles;
 				tinv_doubles += (int64_t)((front_w[q] + front_pad[q]) / DENSE_NB) * DENSE_NB * DENSE_NB;
@@ -1178,6 +1199,7 @@ struct DagArgs {
 	const int64_t *front_tinv; // per front: offset of its diagonal-block inverses in tinv
 	double *tinv;
 	int solve_index;           // number of factorizations run on these counters before this one
+	long long *trace;          // debugging (SPP_DAG_TRACE): per block wall-clock stamps start / children done / end
 };
 
 __device__ __forceinline__ bool dag_wait(const int *flag, int value, int *abort, long long timeout_ticks)
@@ -1387,15 +1409,21 @@ void front_dag_kernel(DagArgs da, FrontArgs fa)
 	const int tid = threadIdx.x;
 	if(tid >= nth)
 		return; // (a barrier does not wait for waves that have ended)
+	if(da.trace && tid == 0)
+		da.trace[4 * blockIdx.x] = wall_clock64();
 	if(cls == 4) {
 		const int G = da.front_team[s], rank = da.rank[blockIdx.x];
 		auto wait_kids = [&]() {
 			if(tid == 0) {
+				if(da.trace)
+					da.trace[4 * blockIdx.x + 1] = wall_clock64();
 				for(int cq = fa.child_ptr[s]; cq < fa.child_ptr[s + 1]; ++ cq)
 					if(!dag_wait(da.done + fa.child_list[cq], da.epoch, da.abort, da.timeout_ticks))
 						break;
 				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+				if(da.trace)
+					da.trace[4 * blockIdx.x + 2] = wall_clock64();
 			}
 		};
 		const int nbar = 1 + 3 * ((fa.front_w[s] + fa.front_pad[s]) / NB);
@@ -1403,11 +1431,15 @@ void front_dag_kernel(DagArgs da, FrontArgs fa)
 			da.timeout_ticks, fsm, wait_kids);
 		if(rank == 0) // (every member released its stores in the last barrier of the team)
 			dag_publish(da.done + s, da.epoch);
+		if(da.trace && tid == 0)
+			da.trace[4 * blockIdx.x + 3] = wall_clock64();
 		return;
 	}
 	// the children's flags are awaited inside the body, after the part of the assembly that does not need them
 	auto wait_children = [&]() {
 		if(tid == 0) {
+			if(da.trace)
+				da.trace[4 * blockIdx.x + 1] = wall_clock64();
 			for(int cq = fa.child_ptr[s]; cq < fa.child_ptr[s + 1]; ++ cq) {
 				const int c = fa.child_list[cq];
 				if(da.front_level[c] >= da.level_first && !dag_wait(da.done + c, da.epoch, da.abort, da.timeout_ticks))
@@ -1415,6 +1447,8 @@ void front_dag_kernel(DagArgs da, FrontArgs fa)
 			}
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			if(da.trace)
+				da.trace[4 * blockIdx.x + 2] = wall_clock64();
 		}
 	};
 	if(cls == 0)
@@ -1426,6 +1460,8 @@ void front_dag_kernel(DagArgs da, FrontArgs fa)
 	else
 		front_body<MID_FRONT_MAX, 1024, true>(s, fa, fsm, wait_children);
 	dag_publish(da.done + s, da.epoch);
+	if(da.trace && tid == 0)
+		da.trace[4 * blockIdx.x + 3] = wall_clock64();
 }
 
 __global__ __launch_bounds__(1024)
@@ -1594,6 +1630,7 @@ static void sparse_enqueue(spp_ctx *ctx, const double *d_vals, double *d_rhs)
 	da.front_tinv = sp->front_tinv.p;
 	da.tinv = sp->team_tinv.p;
 	da.solve_index = 0;
+	da.trace = nullptr;
 	if(dag) {
 		static bool attr = false;
 		if(!attr) {
@@ -1608,9 +1645,47 @@ static void sparse_enqueue(spp_ctx *ctx, const double *d_vals, double *d_rhs)
 		const int32_t skip = 0;
 		da.list = sp->dag_list.p + skip;
 		da.rank = sp->dag_rank.p + skip;
+		static int trace_left = -1;
+		if(trace_left < 0)
+			trace_left = getenv("SPP_DAG_TRACE") ? atoi(getenv("SPP_DAG_TRACE")) : 0;
+		DevBuf<long long> trace_buf;
+		if(trace_left > 0) {
+			trace_buf.reserve((size_t)4 * sp->dag_n);
+			SPP_HIP_CHECK(hipMemsetAsync(trace_buf.p, 0, (size_t)4 * sp->dag_n * sizeof(long long), s));
+			da.trace = trace_buf.p;
+		}
 		if(sp->dag_n > skip)
 			hipLaunchKernelGGL(front_dag_kernel, dim3((unsigned)(sp->dag_n - skip)), dim3(DAG_THREADS), sp->dag_lds, s, da,
 				make_front_args(ctx, sp, d_vals));
+		if(trace_left > 0 && -- trace_left == 0) { // debugging: per level, when its fronts started / had their children / ended (us)
+			std::vector<long long> tr((size_t)4 * sp->dag_n);
+			SPP_HIP_CHECK(hipMemcpyAsync(tr.data(), trace_buf.p, tr.size() * sizeof(long long), hipMemcpyDeviceToHost, s));
+			SPP_HIP_CHECK(hipStreamSynchronize(s));
+			std::vector<int32_t> lst((size_t)sp->dag_n), lev((size_t)sp->n_snodes), cl((size_t)sp->n_snodes);
+			SPP_HIP_CHECK(hipMemcpy(lst.data(), sp->dag_list.p, lst.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+			SPP_HIP_CHECK(hipMemcpy(lev.data(), sp->front_level.p, lev.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+			long long t0 = tr[0];
+			for(size_t b = 0; b < lst.size(); ++ b)
+				if(tr[4 * b])
+					t0 = std::min(t0, tr[4 * b]);
+			for(int64_t l = 0; l < sp->n_levels; ++ l) {
+				double s0 = 1e30, s1 = 0, k1 = 0, e0 = 1e30, e1 = 0, dmax = 0;
+				int cnt = 0, hmax = 0;
+				for(size_t b = 0; b < lst.size(); ++ b) {
+					const int32_t f = lst[b];
+					if(lev[f] != l || !tr[4 * b])
+						continue;
+					++ cnt;
+					const double ts = (tr[4 * b] - t0) * 0.01, tk = (tr[4 * b + 2] - t0) * 0.01, te = (tr[4 * b + 3] - t0) * 0.01;
+					s0 = std::min(s0, ts); s1 = std::max(s1, ts); k1 = std::max(k1, tk); e0 = std::min(e0, te); e1 = std::max(e1, te);
+					dmax = std::max(dmax, te - tk);
+					hmax = std::max(hmax, sp->h_front_h[f]);
+				}
+				fprintf(stderr, "[spp dag] level %2ld: %4d blocks, max h %4d, start %.1f..%.1f, last children-done %.1f, end %.1f..%.1f, longest body after children %.1f us\n",
+					(long)l, cnt, hmax, s0, s1, k1, e0, e1, dmax);
+			}
+		}
+		da.trace = nullptr;
 	}
 	for(int64_t l = first_level; l < sp->n_levels; ++ l) {
 		const int32_t *cp = sp->h_cls_ptr.data() + l * NCLS;
