@@ -440,20 +440,30 @@ void build_schur_plan(spp_ctx *ctx, bool sparse_S, bool mis)
 			// All eight XCDs work in the same neighbourhood of S: consecutive tiles (in tile-row-major order) go to
 			// consecutive XCDs. A tile's camera segments still meet in ONE L2, and the blocks every XCD re-reads
 			// within a band of S now share one working set in the memory-side cache (256 MB) instead of eight.
-			std::vector<int64_t> rank(perm.size()); // running index of the item's tile among the non-empty tiles
-			int64_t r = -1, prev = -1;
-			for(size_t q = 0; q < perm.size(); ++ q) {
+			// The deal is by WORK, not by count: the next tile goes to the XCD with the least work so far (a wave spends a
+			// fixed cost per item plus one gather round per 64 pairs) -- on a banded S every eighth tile can be a diagonal
+			// one, ten times as heavy as its neighbours (config 5 shape: 2.65 ms dealt by count, 1.5 ms by work).
+			std::vector<int32_t> xcd_of(perm.size());
+			int64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+			for(size_t q = 0; q < perm.size();) {
 				const int64_t t = tile_of(perm[q]);
-				if(t != prev) {
-					++ r;
-					prev = t;
-				}
-				rank[perm[q]] = r;
+				size_t e = q;
+				int64_t cost = 0;
+				for(; e < perm.size() && tile_of(perm[e]) == t; ++ e)
+					cost += 2 + (item_end[perm[e]] - item_beg[perm[e]] + 63) / 64;
+				int x = 0;
+				for(int y = 1; y < 8; ++ y)
+					if(load[y] < load[x])
+						x = y;
+				load[x] += cost;
+				for(size_t i = q; i < e; ++ i)
+					xcd_of[perm[i]] = x;
+				q = e;
 			}
-			std::stable_sort(perm.begin(), perm.end(), [&](int32_t x, int32_t y) { return (rank[x] & 7) < (rank[y] & 7); });
+			std::stable_sort(perm.begin(), perm.end(), [&](int32_t x, int32_t y) { return xcd_of[x] < xcd_of[y]; });
 			xb_il.assign(9, 0);
 			for(size_t q = 0; q < perm.size(); ++ q)
-				++ xb_il[(rank[q] & 7) + 1];
+				++ xb_il[xcd_of[q] + 1];
 			for(int x = 0; x < 8; ++ x)
 				xb_il[x + 1] += xb_il[x];
 		}
