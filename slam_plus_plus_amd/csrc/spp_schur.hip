@@ -225,6 +225,9 @@ constexpr int SACC_WAVES = 4; // waves per workgroup
 #ifndef SPP_SACC_RP
 #define SPP_SACC_RP 64 // pairs per round
 #endif
+#ifndef SPP_SACC_GLDS
+#define SPP_SACC_GLDS 1 // 1: the gathered blocks go from L2 / HBM straight into the LDS images (global_load_lds_dwordx4)
+#endif
 
 __device__ __forceinline__ SaccItem sacc_load_item(const SaccItem *__restrict__ items, int32_t idx, int32_t lim)
 {
@@ -253,12 +256,19 @@ void s_accum_kernel(const SaccItem *__restrict__ items, const int32_t *__restric
 	constexpr int PPI = 64 / PCS;               // blocks (pairs) fetched per wave instruction
 	constexpr int RP = SPP_SACC_RP;             // pairs per round: the LDS images hold RP blocks per operand
 	constexpr int NG = (RP + PPI - 1) / PPI;    // instructions per operand and round
-	constexpr int ST = BLK | 1;                 // LDS stride of one block image in doubles (odd)
+	// GLDS: the blocks are fetched by LDS-DMA: no staging registers, no ds_write -- the LDS pipe was the busiest unit of
+	// the kernel (137 LDS instructions per item, a third of the issue cycles). One instruction lands the 16-byte pieces
+	// of its 64 lanes back to back, i.e. PPI whole blocks at their natural stride of BLK doubles: the image is
+	// [pair][BLK], which the per-lane ds_read_b128 of the consumer reads without bank conflicts (36 l mod 64 is
+	// distinct over 16 lanes). The lanes behind the last whole block of an instruction stay masked (their 16 bytes
+	// would land on the next group's first block).
+	constexpr bool GLDS = (PW == 2) && (SPP_SACC_GLDS != 0);
+	constexpr int ST = GLDS ? BLK : (BLK | 1);  // LDS stride of one block image in doubles (odd when staged through registers)
 	constexpr int NE2 = (NE + 1) / 2;           // element pairs of a block
 	constexpr int RS = 2 * NE2 + 2;             // row stride of the reduction image (even: 16-byte rows)
 	constexpr int NSEG = 64 / NE2 < 3 ? 64 / NE2 : 3; // segments of the partial list summed side by side
-	static_assert(2 * RP * ST >= RP * RS, "the reduction image reuses the staging area");
-	__shared__ double lds[SACC_WAVES][2 * RP * ST];
+	constexpr int LW = (2 * RP * ST > RP * RS) ? 2 * RP * ST : RP * RS; // per wave: the staging area, reused by the reduction image
+	__shared__ __attribute__((aligned(16))) double lds[SACC_WAVES][LW];
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
 	// workgroups go round-robin over the 8 XCDs: XCD x works through its own contiguous range of the
 	// items (equal work per range), so that the camera segments of a tile of blocks are fetched into
@@ -307,6 +317,26 @@ void s_accum_kernel(const SaccItem *__restrict__ items, const int32_t *__restric
 			}
 		}
 		// ---- cooperative fetch of up to 64 W and 64 U blocks into the LDS images
+		if constexpr(GLDS) {
+			int32_t ia[NG], ib[NG];
+#pragma unroll
+			for(int g = 0; g < NG; ++ g) {
+				const int p = g * PPI + my_pair; // pair of this round served by this lane
+				ia[g] = __shfl(pa, p & 63);
+				ib[g] = __shfl(pb, p & 63);
+			}
+#pragma unroll
+			for(int g = 0; g < NG; ++ g) {
+				const int p = g * PPI + my_pair;
+				if(my_pair < PPI && p < nround) {
+					__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + (int64_t)ia[g] * BLK + 2 * my_piece),
+						(__attribute__((address_space(3))) void*)(sw + g * PPI * BLK), 16, 0, 0);
+					__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Up + (int64_t)ib[g] * BLK + 2 * my_piece),
+						(__attribute__((address_space(3))) void*)(su + g * PPI * BLK), 16, 0, 0);
+				}
+			}
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		} else {
 		constexpr int GC = (NG < 10) ? NG : 10; // groups in flight at a time (register budget of the 6 x 6 case)
 #pragma unroll
 		for(int g0 = 0; g0 < NG; g0 += GC) {
@@ -346,6 +376,7 @@ void s_accum_kernel(const SaccItem *__restrict__ items, const int32_t *__restric
 					}
 				}
 			}
+		}
 		}
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 		__builtin_amdgcn_wave_barrier();
