@@ -253,12 +253,24 @@ def main():
         upd = ctx.se2_update_device if dof == 3 else ctx.se3_update_device
 
         def gn_resident():
+            marks = [time.perf_counter()] if os.environ.get("BENCH_DEBUG") else None
             d_pw.copy_from(d_pg["poses"])
+            if marks: marks.append(time.perf_counter())
             lin(ne_, d_pg["v0"].ptr, d_pg["v1"].ptr, d_pw.ptr, d_pg["meas"].ptr, r_J0.ptr, r_J1.ptr, r_r.ptr)
+            if marks: marks.append(time.perf_counter())
             ctx.assemble_device(r_J0.ptr, r_J1.ptr, d_in[2].ptr, r_r.ptr, 0.0, r_vals.ptr, r_eta.ptr)
-            if ctx.factor_solve_device(r_vals.ptr, r_eta.ptr) != 0:
+            if marks: marks.append(time.perf_counter())
+            code = ctx.factor_solve_device(r_vals.ptr, r_eta.ptr)
+            if marks: marks.append(time.perf_counter())
+            if code != 0:
                 raise SystemExit("resident GN: factorization failed")
-            return upd(nv_, d_pw.ptr, r_eta.ptr, apply=True)
+            out = upd(nv_, d_pw.ptr, r_eta.ptr, apply=True)
+            if marks:
+                marks.append(time.perf_counter())
+                if marks[-1] - marks[0] > 5e-3:  # where a stalled iteration spent its time (host clock per API call)
+                    print("stalled iteration: copy %.3f linearize %.3f assemble %.3f factor_solve %.3f update+norm %.3f ms" % tuple(
+                        1e3 * (b - a) for a, b in zip(marks[:-1], marks[1:])), file=sys.stderr)
+            return out
 
         ctx.set_profiling(False)
         for _ in range(2):

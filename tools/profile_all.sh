@@ -14,7 +14,7 @@ for w in "$@"; do
 		venice871) dom=gemm_tn_mixed; steps=20;;
 		ladybug49) dom=s_accum_kernel; steps=50;;
 		synthetic10k) dom=s_accum_kernel; steps=5;;
-		*) dom=front_lds_kernel; steps=50;;
+		*) dom=front_dag_kernel; steps=50;;
 	esac
 	echo "== $w"
 	python3 bench.py --workload $w --steps $steps --warmup 3 > profiles/${tag}_${w}_bench_line.json 2> $out/${tag}_${w}_bench.err
