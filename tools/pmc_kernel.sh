@@ -9,6 +9,8 @@ grp[2]="SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_L
 grp[3]="TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum"
 grp[4]="FETCH_SIZE"
 grp[5]="WRITE_SIZE"
+grp[6]="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY"
+grp[7]="GRBM_GUI_ACTIVE GRBM_COUNT"
 for i in $sel; do
   timeout -k 10 120 rocprofv3 --kernel-trace --pmc ${grp[$i]} -d $out/p$i -o run --output-format csv -- python3 bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --cpu-cholmod off > $out/p$i.log 2>&1 || { echo "pass $i failed"; exit 1; }
 done
