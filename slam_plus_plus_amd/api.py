@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libspp_hip.so")
+LIB_PATH = os.environ.get("SPP_LIB") or os.path.join(_HERE, "libspp_hip.so")  # SPP_LIB: another build of the library (A/B experiments)
 
 SPP_OK, SPP_NOT_POSDEF = 0, 1
 MODE_AUTO, MODE_SPARSE, MODE_SCHUR, MODE_SCHUR_SPARSE, MODE_SCHUR_MIS = 0, 1, 2, 3, 4

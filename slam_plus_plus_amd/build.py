@@ -30,7 +30,10 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, lib=None):
+    global LIB
+    if lib:
+        LIB = lib
     if not force and not needs_build():
         return LIB
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
@@ -39,6 +42,7 @@ def build(force=False, verbose=True):
         defs.append("-DSPP_HAVE_SPARSE")
     if os.path.exists(os.path.join(CSRC, "spp_assemble.hip")):
         defs.append("-DSPP_HAVE_ASSEMBLE")
+    defs += os.environ.get("SPP_EXTRA_DEFS", "").split()  # experiments: e.g. SPP_EXTRA_DEFS="-DSPP_MFMA_444=0"
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB] + defs + srcs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

@@ -111,6 +111,24 @@ __device__ __forceinline__ void gemm_tn_tile(const int64_t m0, const int64_t n0,
 		*(double2*)(&As[(p / PPC) * LSTR + (p % PPC) * 2]) = (buf ? ra1 : ra0)[i]; } \
 	_Pragma("unroll") for(int i = 0; i < PB; ++ i) { int p = tid + i * NT; \
 		*(double2*)(&Bs[(p / PPC) * LSTR + (p % PPC) * 2]) = (buf ? rb1 : rb0)[i]; }
+#if SPP_MFMA_444
+	// v_mfma_f64_4x4x4_4b (four independent 4 x 4 x 4 products; lane maps in spp_dense_dev.h): measured on this part at one
+	// instruction (512 flop) per 18 cycles and SIMD = 72 TFLOP/s against one v_mfma_f64_16x16x4 (2048 flop) per 101 cycles =
+	// 48 TFLOP/s (tools/mfma_rate.hip). One instruction forms a 16 x 4 strip of C: the B operand is the 16x16x4 form's own
+	// (k = lane >> 4, 16 rows of C), the A operand four columns of C replicated over the four blocks; strip r of a
+	// 16 x 16 tile lands exactly where accumulator register r of the 16x16x4 form lives (n = 4 r + (lane >> 4)).
+#define SPP_COMPUTE_SLAB() \
+	_Pragma("unroll") for(int kk = 0; kk < BKT / 4; ++ kk) { \
+		double fa[TA]; \
+		_Pragma("unroll") for(int a = 0; a < TA; ++ a) fa[a] = As[(wm + a * 16 + l15) * LSTR + kk * 4 + l4]; \
+		_Pragma("unroll") for(int b = 0; b < TB; ++ b) \
+			_Pragma("unroll") for(int r = 0; r < 4; ++ r) { \
+				const double fb = Bs[(wn + b * 16 + 4 * r + (lane & 3)) * LSTR + kk * 4 + l4]; \
+				_Pragma("unroll") for(int a = 0; a < TA; ++ a) \
+					acc[b][a][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(fb, fa[a], acc[b][a][r], 0, 0, 0); \
+			} \
+	}
+#else
 #define SPP_COMPUTE_SLAB() \
 	_Pragma("unroll") for(int kk = 0; kk < BKT / 4; ++ kk) { \
 		double fa[TA], fb[TB]; \
@@ -120,6 +138,7 @@ __device__ __forceinline__ void gemm_tn_tile(const int64_t m0, const int64_t n0,
 			_Pragma("unroll") for(int a = 0; a < TA; ++ a) \
 				acc[b][a] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[b], fa[a], acc[b][a], 0, 0, 0); \
 	}
+#endif
 
 	if(DEPTH == 1) {
 		// one slab in flight (fewer staging registers: no scratch at 128 VGPRs, two workgroups per CU)
@@ -214,7 +233,10 @@ __device__ __forceinline__ void upper_tile_of(int64_t t, int nt, int &ti, int &t
 	ti = (int)(t - (int64_t)j * (j + 1) / 2);
 }
 
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))
+#ifndef SPP_MIXED_WAVES
+#define SPP_MIXED_WAVES 8 // waves per SIMD the register allocator leaves room for: 8 = two workgroups per CU at 64 VGPRs, 4 = one at 128
+#endif
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(SPP_MIXED_WAVES, SPP_MIXED_WAVES)))
 void gemm_tn_mixed_kernel(int64_t M, int64_t N, int K, const double *__restrict__ A, int64_t lda,
 	const double *B, int64_t ldb, double *C, int64_t ldc, int nt, int64_t n128)
 {
