@@ -40,6 +40,9 @@
 #include <string>
 #include <vector>
 #include <cstring>
+#include <cstdlib>
+#include <algorithm>
+#include <thread>
 
 #include "slam/LinearSolverTags.h" // CBlockwiseLinearSolverTag, CUberBlockMatrix, Eigen
 #include "spp_hip.h"
@@ -198,11 +201,48 @@ protected:
 	 */
 	bool Flatten_Values(const CUberBlockMatrix &r_lambda)
 	{
-		size_t n_blk = 0;
 		const size_t n = r_lambda.n_BlockColumn_Num();
 		if(n != m_dim.size())
 			return false;
-		for(size_t i = 0; i < n; ++ i) {
+		// Large systems (Venice-sized Lambda: 447 MB, 3.4 M blocks) are copied by several host threads, each a contiguous
+		// range of block columns: reading a CUberBlockMatrix through its const interface is thread-safe, every thread
+		// writes its own range of the staging buffer and the per-block checks stay with the copy.
+		size_t n_threads = 1;
+		if(m_n_vals * sizeof(double) >= (size_t(32) << 20)) {
+			n_threads = std::thread::hardware_concurrency();
+			n_threads = (n_threads > 16)? 16 : ((n_threads < 1)? 1 : n_threads);
+		}
+		if(const char *p_s_env = getenv("SPP_ADAPTER_FLATTEN_THREADS")) // (tests: the threaded copy on small systems too)
+			n_threads = size_t((atoi(p_s_env) > 0)? atoi(p_s_env) : 1);
+		if(n_threads == 1)
+			return Flatten_Columns(r_lambda, 0, n);
+		std::vector<char> ok(n_threads, 0);
+		std::vector<std::thread> workers;
+		for(size_t t = 0; t < n_threads; ++ t) {
+			// equal numbers of stored blocks per thread (m_col_ptr is the running block count)
+			const int64_t n_b0 = int64_t(m_row_idx.size()) * int64_t(t) / int64_t(n_threads),
+				n_b1 = int64_t(m_row_idx.size()) * int64_t(t + 1) / int64_t(n_threads);
+			const size_t c0 = (t == 0)? 0 : size_t(std::lower_bound(m_col_ptr.begin(), m_col_ptr.end(), n_b0) - m_col_ptr.begin());
+			const size_t c1 = (t + 1 == n_threads)? n : size_t(std::lower_bound(m_col_ptr.begin(), m_col_ptr.end(), n_b1) - m_col_ptr.begin());
+			workers.push_back(std::thread([this, &r_lambda, &ok, t, c0, c1]() { ok[t] = Flatten_Columns(r_lambda, c0, (c1 < c0)? c0 : c1)? 1 : 0; }));
+		}
+		bool b_ok = true;
+		for(size_t t = 0; t < n_threads; ++ t) {
+			workers[t].join();
+			b_ok = b_ok && ok[t] != 0;
+		}
+		return b_ok;
+	}
+
+	/**
+	 *	@brief copies the blocks of block columns [n_first, n_end) (a worker of Flatten_Values())
+	 */
+	bool Flatten_Columns(const CUberBlockMatrix &r_lambda, size_t n_first, size_t n_end) const
+	{
+		if(n_first >= n_end)
+			return true;
+		size_t n_blk = size_t(m_col_ptr[n_first]);
+		for(size_t i = n_first; i < n_end; ++ i) {
 			if(int32_t(r_lambda.n_BlockColumn_Column_Num(i)) != m_dim[i])
 				return false;
 			for(size_t j = 0, m = r_lambda.n_BlockColumn_Block_Num(i); j < m; ++ j) {

@@ -72,12 +72,12 @@ def pytest_sessionstart(session):
     ref_dir = os.path.join(ROOT, "oracle", "_ref")
     env = dict(os.environ, OMP_NUM_THREADS="1")
 
-    def run(key, name, args, tmp):
+    def run(key, name, args, tmp, extra_env=None):
         exe = os.path.join(ref_dir, name)
         if not os.path.exists(exe):
             return
         try:
-            p = subprocess.run([exe] + args, cwd=tmp, env=env, capture_output=True, text=True, timeout=300)
+            p = subprocess.run([exe] + args, cwd=tmp, env=dict(env, **(extra_env or {})), capture_output=True, text=True, timeout=300)
             DROPIN_RESULTS[key] = (p.returncode, p.stdout, p.stderr, sorted(os.listdir(tmp)))
             sol = os.path.join(tmp, "solution.txt")
             if os.path.exists(sol) and os.path.getsize(sol) < (8 << 20):
@@ -91,6 +91,9 @@ def pytest_sessionstart(session):
                             ("slam_simple_hip", "slam_simple_hip", [])):
         with tempfile.TemporaryDirectory() as tmp:
             run(key, name, args, tmp)
+    # the adapter's threaded flatten (taken by itself from 32 MB of Lambda on) forced onto a small system
+    with tempfile.TemporaryDirectory() as tmp:
+        run("dropin_driver_ba_mt", "dropin_driver", ["ba", "16", "600", "1"], tmp, {"SPP_ADAPTER_FLATTEN_THREADS": "5"})
     # the reference's applications, sources untouched: slam_plus_plus (src/slam_app) and ba_iface_example, each
     # built twice by `make -C oracle apps` -- *_hip with the shim directory first on the include path, *_ref
     # without it -- on the same generated graph files (scripts/tests/unit_tests.sh style: iterations + chi2)

@@ -38,6 +38,17 @@ def test_reference_levenberg_marquardt_ba_with_hip_solver_matches_reference_schu
     assert float(out.split("max_abs_diff")[1].split()[0]) < 1e-3, out
 
 
+def test_threaded_flatten_of_the_adapter_gives_the_same_result():
+    """include/spp_adapter.h copies a large Lambda into the staging buffer with several host threads (one contiguous range
+    of block columns each); SPP_ADAPTER_FLATTEN_THREADS forces that path on the small LM / BA system of the test above."""
+    if "dropin_driver_ba_mt" not in DROPIN_RESULTS:
+        pytest.skip("oracle/_ref/dropin_driver not built")
+    rc, out, err, _ = DROPIN_RESULTS["dropin_driver_ba_mt"]
+    assert rc == 0, (rc, out, err)
+    assert float(out.split("max_abs_diff")[1].split()[0]) < 1e-10, out
+    assert out == DROPIN_RESULTS["dropin_driver_ba"][1], "one thread and five threads must flatten the same Lambda"
+
+
 def test_unmodified_slam_simple_example_runs_on_the_hip_solver():
     if "slam_simple_hip" not in DROPIN_RESULTS:
         pytest.skip("oracle/_ref/slam_simple_hip not built")
