@@ -738,6 +738,7 @@ struct FrontArgs {
 	const double *vals;
 	double *fronts, *vbuf;
 	int *info;
+	long long *trace; // debugging: stamps 4 (extend-add done), 5 (factored), 6 (written back) of the block's eight
 };
 
 struct NoWait { __device__ __forceinline__ void operator()() const { } };
@@ -822,6 +823,8 @@ __device__ __forceinline__ void front_body(const int s, const FrontArgs &fa, dou
 		}
 		__syncthreads();
 	}
+	if(fa.trace && tid == 0)
+		fa.trace[8 * blockIdx.x + 4] = wall_clock64();
 	// ---- blocked partial factorization
 	const int npan = w16 >> 4;
 	for(int J = 0; J < npan; ++ J) {
@@ -941,6 +944,8 @@ __device__ __forceinline__ void front_body(const int s, const FrontArgs &fa, dou
 		}
 		__syncthreads();
 	}
+	if(fa.trace && tid == 0)
+		fa.trace[8 * blockIdx.x + 5] = wall_clock64();
 	if(GMEM)
 		return; // factored in place
 	// ---- write back the upper triangle in the plain layout
@@ -949,6 +954,8 @@ __device__ __forceinline__ void front_body(const int s, const FrontArgs &fa, dou
 		if(r <= c)
 			F[r + (int64_t)c * ld] = T[padded(r, w, pad) + padded(c, w, pad) * TSF];
 	}
+	if(fa.trace && tid == 0)
+		fa.trace[8 * blockIdx.x + 6] = wall_clock64();
 }
 
 template <int HP, int NTH, bool GMEM>
@@ -1410,20 +1417,20 @@ void front_dag_kernel(DagArgs da, FrontArgs fa)
 	if(tid >= nth)
 		return; // (a barrier does not wait for waves that have ended)
 	if(da.trace && tid == 0)
-		da.trace[4 * blockIdx.x] = wall_clock64();
+		da.trace[8 * blockIdx.x] = wall_clock64();
 	if(cls == 4) {
 		const int G = da.front_team[s], rank = da.rank[blockIdx.x];
 		auto wait_kids = [&]() {
 			if(tid == 0) {
 				if(da.trace)
-					da.trace[4 * blockIdx.x + 1] = wall_clock64();
+					da.trace[8 * blockIdx.x + 1] = wall_clock64();
 				for(int cq = fa.child_ptr[s]; cq < fa.child_ptr[s + 1]; ++ cq)
 					if(!dag_wait(da.done + fa.child_list[cq], da.epoch, da.abort, da.timeout_ticks))
 						break;
 				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 				if(da.trace)
-					da.trace[4 * blockIdx.x + 2] = wall_clock64();
+					da.trace[8 * blockIdx.x + 2] = wall_clock64();
 			}
 		};
 		const int nbar = 1 + 3 * ((fa.front_w[s] + fa.front_pad[s]) / NB);
@@ -1432,14 +1439,14 @@ void front_dag_kernel(DagArgs da, FrontArgs fa)
 		if(rank == 0) // (every member released its stores in the last barrier of the team)
 			dag_publish(da.done + s, da.epoch);
 		if(da.trace && tid == 0)
-			da.trace[4 * blockIdx.x + 3] = wall_clock64();
+			da.trace[8 * blockIdx.x + 3] = wall_clock64();
 		return;
 	}
 	// the children's flags are awaited inside the body, after the part of the assembly that does not need them
 	auto wait_children = [&]() {
 		if(tid == 0) {
 			if(da.trace)
-				da.trace[4 * blockIdx.x + 1] = wall_clock64();
+				da.trace[8 * blockIdx.x + 1] = wall_clock64();
 			for(int cq = fa.child_ptr[s]; cq < fa.child_ptr[s + 1]; ++ cq) {
 				const int c = fa.child_list[cq];
 				if(da.front_level[c] >= da.level_first && !dag_wait(da.done + c, da.epoch, da.abort, da.timeout_ticks))
@@ -1448,7 +1455,7 @@ void front_dag_kernel(DagArgs da, FrontArgs fa)
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 			if(da.trace)
-				da.trace[4 * blockIdx.x + 2] = wall_clock64();
+				da.trace[8 * blockIdx.x + 2] = wall_clock64();
 		}
 	};
 	if(cls == 0)
@@ -1461,7 +1468,7 @@ void front_dag_kernel(DagArgs da, FrontArgs fa)
 		front_body<MID_FRONT_MAX, 1024, true>(s, fa, fsm, wait_children);
 	dag_publish(da.done + s, da.epoch);
 	if(da.trace && tid == 0)
-		da.trace[4 * blockIdx.x + 3] = wall_clock64();
+		da.trace[8 * blockIdx.x + 3] = wall_clock64();
 }
 
 __global__ __launch_bounds__(1024)
@@ -1522,6 +1529,7 @@ static FrontArgs make_front_args(spp_ctx *ctx, SparsePlan *sp, const double *d_v
 	fa.fronts = sp->fronts.p;
 	fa.vbuf = sp->vbuf.p;
 	fa.info = ctx->dense.info.p;
+	fa.trace = nullptr;
 	return fa;
 }
 
@@ -1650,15 +1658,17 @@ static void sparse_enqueue(spp_ctx *ctx, const double *d_vals, double *d_rhs)
 			trace_left = getenv("SPP_DAG_TRACE") ? atoi(getenv("SPP_DAG_TRACE")) : 0;
 		DevBuf<long long> trace_buf;
 		if(trace_left > 0) {
-			trace_buf.reserve((size_t)4 * sp->dag_n);
-			SPP_HIP_CHECK(hipMemsetAsync(trace_buf.p, 0, (size_t)4 * sp->dag_n * sizeof(long long), s));
+			trace_buf.reserve((size_t)8 * sp->dag_n);
+			SPP_HIP_CHECK(hipMemsetAsync(trace_buf.p, 0, (size_t)8 * sp->dag_n * sizeof(long long), s));
 			da.trace = trace_buf.p;
 		}
-		if(sp->dag_n > skip)
-			hipLaunchKernelGGL(front_dag_kernel, dim3((unsigned)(sp->dag_n - skip)), dim3(DAG_THREADS), sp->dag_lds, s, da,
-				make_front_args(ctx, sp, d_vals));
+		if(sp->dag_n > skip) {
+			FrontArgs fa = make_front_args(ctx, sp, d_vals);
+			fa.trace = da.trace;
+			hipLaunchKernelGGL(front_dag_kernel, dim3((unsigned)(sp->dag_n - skip)), dim3(DAG_THREADS), sp->dag_lds, s, da, fa);
+		}
 		if(trace_left > 0 && -- trace_left == 0) { // debugging: per level, when its fronts started / had their children / ended (us)
-			std::vector<long long> tr((size_t)4 * sp->dag_n);
+			std::vector<long long> tr((size_t)8 * sp->dag_n);
 			SPP_HIP_CHECK(hipMemcpyAsync(tr.data(), trace_buf.p, tr.size() * sizeof(long long), hipMemcpyDeviceToHost, s));
 			SPP_HIP_CHECK(hipStreamSynchronize(s));
 			std::vector<int32_t> lst((size_t)sp->dag_n), lev((size_t)sp->n_snodes), cl((size_t)sp->n_snodes);
@@ -1666,23 +1676,29 @@ static void sparse_enqueue(spp_ctx *ctx, const double *d_vals, double *d_rhs)
 			SPP_HIP_CHECK(hipMemcpy(lev.data(), sp->front_level.p, lev.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
 			long long t0 = tr[0];
 			for(size_t b = 0; b < lst.size(); ++ b)
-				if(tr[4 * b])
-					t0 = std::min(t0, tr[4 * b]);
+				if(tr[8 * b])
+					t0 = std::min(t0, tr[8 * b]);
 			for(int64_t l = 0; l < sp->n_levels; ++ l) {
-				double s0 = 1e30, s1 = 0, k1 = 0, e0 = 1e30, e1 = 0, dmax = 0;
+				double s0 = 1e30, s1 = 0, k1 = 0, e0 = 1e30, e1 = 0, dmax = 0, ph[4] = {0, 0, 0, 0};
 				int cnt = 0, hmax = 0;
 				for(size_t b = 0; b < lst.size(); ++ b) {
 					const int32_t f = lst[b];
-					if(lev[f] != l || !tr[4 * b])
+					if(lev[f] != l || !tr[8 * b])
 						continue;
 					++ cnt;
-					const double ts = (tr[4 * b] - t0) * 0.01, tk = (tr[4 * b + 2] - t0) * 0.01, te = (tr[4 * b + 3] - t0) * 0.01;
+					const double ts = (tr[8 * b] - t0) * 0.01, tk = (tr[8 * b + 2] - t0) * 0.01, te = (tr[8 * b + 3] - t0) * 0.01;
 					s0 = std::min(s0, ts); s1 = std::max(s1, ts); k1 = std::max(k1, tk); e0 = std::min(e0, te); e1 = std::max(e1, te);
+					if(te - tk > dmax && tr[8 * b + 4]) { // phases of the front with the longest body: extend-add, factor, write-back, publish
+						ph[0] = (tr[8 * b + 4] - tr[8 * b + 2]) * 0.01;
+						ph[1] = (tr[8 * b + 5] - tr[8 * b + 4]) * 0.01;
+						ph[2] = tr[8 * b + 6] ? (tr[8 * b + 6] - tr[8 * b + 5]) * 0.01 : 0;
+						ph[3] = (tr[8 * b + 3] - (tr[8 * b + 6] ? tr[8 * b + 6] : tr[8 * b + 5])) * 0.01;
+					}
 					dmax = std::max(dmax, te - tk);
 					hmax = std::max(hmax, sp->h_front_h[f]);
 				}
-				fprintf(stderr, "[spp dag] level %2ld: %4d blocks, max h %4d, start %.1f..%.1f, last children-done %.1f, end %.1f..%.1f, longest body after children %.1f us\n",
-					(long)l, cnt, hmax, s0, s1, k1, e0, e1, dmax);
+				fprintf(stderr, "[spp dag] level %2ld: %4d blocks, max h %4d, start %.1f..%.1f, last children-done %.1f, end %.1f..%.1f, longest body after children %.1f us (extend-add %.1f, factor %.1f, write-back %.1f, publish %.1f)\n",
+					(long)l, cnt, hmax, s0, s1, k1, e0, e1, dmax, ph[0], ph[1], ph[2], ph[3]);
 			}
 		}
 		da.trace = nullptr;
