@@ -459,15 +459,18 @@ def main():
         sbytes, fflops = float(ctx.info("SOLVE_BYTES")), float(ctx.info("FACTOR_FLOPS"))
         if fs_ms > 0:
             traffic, traffic_src = pmc_traffic(args.workload)
-            out["roofline"] = {"bound": "hbm", "kernel": "spp::front_lds_kernel / front_fwd_kernel / front_bwd_kernel (supernodal multifrontal "
-                               "factor + triangular solves, one launch per tree level and front size class)",
+            out["roofline"] = {"bound": "hbm", "kernel": "spp::front_dag_kernel / front_bwd_dag_kernel (supernodal multifrontal factor + backward "
+                               "substitution, the whole assembly tree in ONE launch each: a workgroup per front -- a team of "
+                               "workgroups per big front -- waits for its children's / its parent's flag; the forward "
+                               "substitution rides through the factorization)",
                                "achieved": sbytes / (fs_ms * 1e-3) * 1e-9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                "frac": sbytes / (fs_ms * 1e-3) * 1e-9 / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": traffic_src,
                                "algorithmic_bytes": sbytes, "factor_flops": fflops, "ms": fs_ms,
                                "mfma_frac": fflops / (max(phase["factor"], 1e-9) * 1e-3) * 1e-12 / PEAK_FP64_MFMA_TFLOPS,
                                "tree_levels": int(ctx.info("N_LEVELS")), "supernodes": int(ctx.info("N_SUPERNODES")),
-                               "note": "LATENCY-bound, not bandwidth-bound: a few MB of factor spread over %d tree levels; neither "
-                                       "roofline is approached at this size (SURVEY 7.3, 8d)" % int(ctx.info("N_LEVELS"))}
+                               "note": "LATENCY-bound, not bandwidth-bound: a few MB of factor whose critical path is the heaviest "
+                                       "root-to-leaf chain of fronts over %d tree levels; neither roofline is approached at this "
+                                       "size (SURVEY 7.3, 8d)" % int(ctx.info("N_LEVELS"))}
     # ---- the drop-in boundary's host-pointer entry (spp_factor_solve): Lambda in the ctx's page-locked staging buffer
     # (where the adapter flattens it) -> H2D -> solve -> D2H of the solution; never `value`
     if world == 1:

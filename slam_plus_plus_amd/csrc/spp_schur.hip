@@ -242,8 +242,11 @@ __device__ __forceinline__ SaccItem sacc_load_item(const SaccItem *__restrict__ 
 	return r;
 }
 
+#ifndef SPP_SACC_EU
+#define SPP_SACC_EU 2 // waves per SIMD the register allocator leaves room for (2: 256 VGPRs; the LDS images allow 8 waves per CU anyway)
+#endif
 template <int DP, int DL>
-__global__ __launch_bounds__(SACC_WAVES * 64)
+__global__ __launch_bounds__(SACC_WAVES * 64) __attribute__((amdgpu_waves_per_eu(SPP_SACC_EU, SPP_SACC_EU)))
 void s_accum_kernel(const SaccItem *__restrict__ items, const int32_t *__restrict__ xcd_beg, int chunk,
 	const int32_t *__restrict__ pair_a, const int32_t *__restrict__ pair_b,
 	const double *__restrict__ W, const double *__restrict__ Up, const double *__restrict__ vals,
