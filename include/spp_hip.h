@@ -172,6 +172,13 @@ int spp_assemble_get_structure(const spp_ctx *ctx, int64_t *h_col_ptr, int64_t *
 	int64_t *h_blk_off);
 int spp_assemble_device(spp_ctx *ctx, const double *d_J0, const double *d_J1,
 	const double *d_Omega, const double *d_r, double damping, double *d_vals_out, double *d_eta_out);
+/* Robust edges (the reference's b_is_robust_edge branch of Calculate_Hessians_v2, include/slam/BaseTypes_Binary.h:768-848;
+ * kernels and mix-ins include/slam/RobustUtils.h): d_w holds ONE weight per edge -- the value of the edge's
+ * f_RobustWeight(r), evaluated by the caller -- and every following spp_assemble_device applies it exactly where the
+ * reference does: H01 and H00 carry w once (T = J0^T Omega w), the first vertex's right-hand side w TWICE (T r w),
+ * H11 and the second vertex's right-hand side once. The array is NOT copied (it must stay valid); NULL restores plain
+ * edges; spp_assemble_analyze resets it. */
+int spp_assemble_set_edge_weights(spp_ctx *ctx, const double *d_w);
 
 /* ---- device memory helpers for hosts without a HIP runtime of their own ---------------------------- */
 /* ---- on-device geometry of 2D pose graphs (CEdgePose2D) --------------------------

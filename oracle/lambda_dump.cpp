@@ -18,7 +18,9 @@
  * transposed. For BA a second record is taken through CNonlinearSolver_Lambda_LM: Lambda with the
  * Levenberg-Marquardt damping on its diagonal (include/slam/NonlinearSolver_Lambda_LM.h:228-239).
  *
- * usage: lambda_dump se2|se3|ba <out.txt>     (text, %.17g; tools/make_golden_lambda.py -> tests/golden/*_lambda.npz)
+ * A fourth record (ba_robust): the same BA problem with ROBUST edges (Huber weights on Omega, BaseTypes_Binary.h:768-848).
+ *
+ * usage: lambda_dump se2|se3|ba|ba_robust <out.txt>     (text, %.17g; tools/make_golden_lambda.py -> tests/golden/*_lambda.npz)
  * Built by oracle/Makefile (target `lambda_dump`) into oracle/_ref/; contains reference code, never enters git.
  */
 #include <stdio.h>
@@ -33,6 +35,7 @@
 #include "slam/SE3_Types.h"
 #include "slam/BA_Types.h"
 #include "slam/NonlinearSolver_Lambda_LM.h"
+#include "slam/RobustUtils.h"
 
 static FILE *g_p_out = 0;
 static const char *g_p_s_record_name = "LAMBDA";
@@ -330,10 +333,87 @@ static int Run_BA()
 	return 0;
 }
 
+/**
+ *	the reference's BA projection edge (include/slam/BA_Types.h:403-560) declared ROBUST the way include/slam/RobustUtils.h:112-125
+ *	prescribes -- the CBaseEdge::Robust option of CBaseEdgeImpl plus a CRobustify_* mix-in that supplies f_RobustWeight() --,
+ *	here with a Huber kernel on the error norm at a scale of 3/4 pixel so that about half of the test graph's edges get a
+ *	weight below one. Every number it produces comes out of the reference's own code: CBAJacobians::Project_P2C, the
+ *	kernel, and Calculate_Hessians_v2's robust branch (include/slam/BaseTypes_Binary.h:768-848).
+ */
+class CEdgeP2C3D_Huber : public CBaseEdgeImpl<CEdgeP2C3D_Huber, MakeTypelist(CVertexCam, CVertexXYZ), 2, 2, CBaseEdge::Robust>,
+	public CRobustify_ErrorNorm_Default<CCTFraction<3, 4>, CHuberLossd> {
+public:
+	typedef CBaseEdgeImpl<CEdgeP2C3D_Huber, MakeTypelist(CVertexCam, CVertexXYZ), 2, 2, CBaseEdge::Robust> _TyBase;
+	__GRAPH_TYPES_ALIGN_OPERATOR_NEW
+
+	inline CEdgeP2C3D_Huber()
+	{}
+
+	template <class CSystem>
+	CEdgeP2C3D_Huber(size_t n_node1, size_t n_node0, const Eigen::Vector2d &v_delta,
+		const Eigen::Matrix2d &r_t_inv_sigma, CSystem &r_system)
+		:_TyBase(n_node0, n_node1, v_delta, r_t_inv_sigma, CBaseEdge::explicitly_initialized_vertices, r_system)
+	{}
+
+	inline void Calculate_Jacobians_Expectation_Error(Eigen::Matrix<double, 2, 6> &r_t_jacobian0,
+		Eigen::Matrix<double, 2, 3> &r_t_jacobian1, Eigen::Matrix<double, 2, 1> &r_v_expectation,
+		Eigen::Matrix<double, 2, 1> &r_v_error) const
+	{
+		CBAJacobians::Project_P2C(m_p_vertex0->r_v_State(), m_p_vertex0->v_Intrinsics(),
+			m_p_vertex1->r_v_State(), r_v_expectation, r_t_jacobian0, r_t_jacobian1);
+		r_v_error = m_v_measurement - r_v_expectation;
+	}
+
+	inline double f_Chi_Squared_Error() const
+	{
+		Eigen::Vector2d v_error;
+		CBAJacobians::Project_P2C(m_p_vertex0->r_v_State(), m_p_vertex0->v_Intrinsics(), m_p_vertex1->r_v_State(), v_error);
+		v_error -= m_v_measurement;
+		return (v_error.transpose() * m_t_sigma_inv).dot(v_error) * f_RobustWeight(v_error);
+	}
+};
+
+typedef MakeTypelist_Safe((CEdgeP2C3D_Huber)) TBARobustEdgeTypelist;
+typedef CFlatSystem<CBaseVertex, TBAVertexTypelist, CEdgeP2C3D_Huber, TBARobustEdgeTypelist> CBARobustSystem;
+
+/** the BA problem of Run_BA() with robust edges: per edge J0 J1 Omega r AND the robust weight, then Lambda / eta */
+static int Run_BA_Robust()
+{
+	typedef CLinearSolver_Recorder<CBARobustSystem::_TyHessianMatrixBlockList> CSolver;
+	TBA problem;
+	Generate_BA(problem);
+	CBARobustSystem system;
+	CNonlinearSolver_Lambda<CBARobustSystem, CSolver> solver(system);
+	for(size_t id = 0; id < problem.is_cam.size(); ++ id) {
+		if(problem.is_cam[id])
+			system.r_Get_Vertex<CVertexCam>(id, problem.cam_state[id]);
+		else
+			system.r_Get_Vertex<CVertexXYZ>(id, problem.pt_state[id]);
+	}
+	Eigen::Matrix2d information;
+	information << 1.0, 0.1, 0.1, 0.8;
+	std::vector<const CEdgeP2C3D_Huber*> edges;
+	for(size_t i = 0; i < problem.obs.size(); ++ i)
+		edges.push_back(&system.r_Add_Edge(CEdgeP2C3D_Huber(problem.obs[i].n_pt_id, problem.obs[i].n_cam_id, problem.obs[i].z, information, system)));
+	fprintf(g_p_out, "GRAPH ba_robust %lu %lu 2 6 3\n", (unsigned long)system.r_Vertex_Pool().n_Size(), (unsigned long)edges.size());
+	for(size_t i = 0; i < edges.size(); ++ i) {
+		Dump_Edge<CEdgeP2C3D_Huber, 2, 6, 3>(*edges[i]);
+		Eigen::Matrix<double, 2, 6> J0;
+		Eigen::Matrix<double, 2, 3> J1;
+		Eigen::Matrix<double, 2, 1> v_expectation, v_error;
+		edges[i]->Calculate_Jacobians_Expectation_Error(J0, J1, v_expectation, v_error);
+		fprintf(g_p_out, "W %.17g\n", edges[i]->f_RobustWeight(v_error)); // the weight of the edge dumped in the line above
+	}
+	g_p_s_record_name = "LAMBDA_ROBUST";
+	g_n_records_left = 1;
+	solver.Optimize(2, 1e-9); // Gauss-Newton: the robustly weighted Lambda of the first linear solve
+	return 0;
+}
+
 int main(int n_arg_num, const char **p_arg_list)
 {
 	if(n_arg_num < 3) {
-		fprintf(stderr, "usage: lambda_dump se2|se3|ba <out.txt>\n");
+		fprintf(stderr, "usage: lambda_dump se2|se3|ba|ba_robust <out.txt>\n");
 		return 1;
 	}
 	g_p_out = fopen(p_arg_list[2], "w");
@@ -347,6 +427,8 @@ int main(int n_arg_num, const char **p_arg_list)
 			n_result = Run_SE3();
 		else if(!strcmp(p_arg_list[1], "ba"))
 			n_result = Run_BA();
+		else if(!strcmp(p_arg_list[1], "ba_robust"))
+			n_result = Run_BA_Robust();
 	} catch(std::exception &r_exc) {
 		fprintf(stderr, "error: %s\n", r_exc.what());
 		n_result = 3;

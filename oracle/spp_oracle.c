@@ -39,8 +39,11 @@ static void mm_nn(int m, int n, int k, const double *A, const double *B, double 
  *                  :810-815  H00 = (T J0).selfadjointView<Upper>()  (upper half mirrored)
  *                  :819-823  g0 = T r
  *                  :825-846  H11 = (J1^T Omega J1).selfadjointView<Upper>(), g1 = J1^T (Omega r) */
-void orc_edge_hessians(int d0, int d1, int rd, int64_t ne,
-	const double *J0, const double *J1, const double *Om, const double *r,
+/* Robust edges (b_is_robust_edge, BaseTypes_Binary.h:768-774, 821-846): one weight w per edge, the value of the edge's
+ * f_RobustWeight(r). T = J0^T Omega w replaces J0^T Omega (so H01 and H00 carry w once), g0 = T r w -- w TWICE, as the
+ * reference writes it --, H11 = J1^T Omega J1 w and g1 = J1^T (Omega r) w. w == NULL: plain edges. */
+void orc_edge_hessians_w(int d0, int d1, int rd, int64_t ne,
+	const double *J0, const double *J1, const double *Om, const double *r, const double *w,
 	const uint8_t *reversed,
 	double *H01, double *H00, double *H11, double *g0, double *g1)
 {
@@ -49,6 +52,9 @@ void orc_edge_hessians(int d0, int d1, int rd, int64_t ne,
 		const double *j0 = J0 + e * rd * d0, *j1 = J1 + e * rd * d1;
 		const double *om = Om + e * rd * rd, *re = r + e * rd;
 		mm_tn(d0, rd, rd, j0, om, T); /* T = J0^T Om  (d0 x rd) */
+		if(w)
+			for(int i = 0; i < d0 * rd; ++ i)
+				T[i] *= w[e]; /* :771 t_H0_sigma_inv = J0^T * Sigma^-1 * w */
 		double *h01 = H01 + e * d0 * d1;
 		if(reversed && reversed[e]) {
 			/* t_HtSiH (d1 x d0) = J1^T * T^T */
@@ -67,16 +73,33 @@ void orc_edge_hessians(int d0, int d1, int rd, int64_t ne,
 			for(int i = 0; i < d0; ++ i)
 				h00[i + j * d0] = (i <= j)? tmp[i + j * d0] : tmp[j + i * d0];
 		mm_nn(d0, 1, rd, T, re, g0 + e * d0);
+		if(w)
+			for(int i = 0; i < d0; ++ i)
+				g0[e * d0 + i] *= w[e]; /* :821 t_H0_sigma_inv * v_error * w */
 		/* J1^T Om J1: Eigen evaluates (J1^T * Om) * J1 left to right */
 		mm_tn(d1, rd, rd, j1, om, T1);
 		mm_nn(d1, d1, rd, T1, j1, tmp);
+		if(w)
+			for(int i = 0; i < d1 * d1; ++ i)
+				tmp[i] *= w[e]; /* :829, :835 J1^T Sigma^-1 J1 * w */
 		double *h11 = H11 + e * d1 * d1;
 		for(int j = 0; j < d1; ++ j)
 			for(int i = 0; i < d1; ++ i)
 				h11[i + j * d1] = (i <= j)? tmp[i + j * d1] : tmp[j + i * d1];
 		mm_nn(rd, 1, rd, om, re, Or);
 		mm_tn(d1, 1, rd, j1, Or, g1 + e * d1);
+		if(w)
+			for(int i = 0; i < d1; ++ i)
+				g1[e * d1 + i] *= w[e]; /* :844 J1^T (Sigma^-1 r) * w */
 	}
+}
+
+void orc_edge_hessians(int d0, int d1, int rd, int64_t ne,
+	const double *J0, const double *J1, const double *Om, const double *r,
+	const uint8_t *reversed,
+	double *H01, double *H00, double *H11, double *g0, double *g1)
+{
+	orc_edge_hessians_w(d0, d1, rd, ne, J0, J1, Om, r, 0, reversed, H01, H00, H11, g0, g1);
 }
 
 /* ---- a-2: reduction plan -------------------------------------------------------------------

@@ -102,8 +102,9 @@ def lambda_structure(prob):
     return st, eblk, dblk, rev
 
 
-def assemble(prob, damping=None):
-    """Lambda (upper block triangle) and eta from per-edge Jacobians, in the reference's order."""
+def assemble(prob, damping=None, weights=None):
+    """Lambda (upper block triangle) and eta from per-edge Jacobians, in the reference's order.
+    weights: one robust weight per edge (the reference's b_is_robust_edge branch, BaseTypes_Binary.h:768-848)."""
     L = lib()
     st, eblk, dblk, rev = lambda_structure(prob)
     ne, d0, d1, rd = prob.v0.size, prob.d0, prob.d1, prob.rd
@@ -117,8 +118,14 @@ def assemble(prob, damping=None):
     g0 = np.empty(ne * d0)
     g1 = np.empty(ne * d1)
     rev8 = np.ascontiguousarray(rev, dtype=np.uint8)
-    L.orc_edge_hessians(d0, d1, rd, i64(ne), _p(J0), _p(J1), _p(Om), _p(r), _p(rev8),
-                        _p(H01), _p(H00), _p(H11), _p(g0), _p(g1))
+    if weights is None:
+        L.orc_edge_hessians(d0, d1, rd, i64(ne), _p(J0), _p(J1), _p(Om), _p(r), _p(rev8),
+                            _p(H01), _p(H00), _p(H11), _p(g0), _p(g1))
+    else:
+        wts = np.ascontiguousarray(weights, dtype=np.float64)
+        assert wts.shape == (ne,)
+        L.orc_edge_hessians_w(d0, d1, rd, i64(ne), _p(J0), _p(J1), _p(Om), _p(r), _p(wts), _p(rev8),
+                              _p(H01), _p(H00), _p(H11), _p(g0), _p(g1))
     nv = prob.dim.size
     dim = np.asarray(prob.dim, dtype=np.int64)
     # one source pool: [H01 | H00 | H11 | unary identity]

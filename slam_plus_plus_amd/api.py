@@ -30,7 +30,7 @@ EXPORTS = [
     "spp_analyze", "spp_set_shard", "spp_get_info", "spp_get_ordering", "spp_factor_solve",
     "spp_factor_solve_device", "spp_schur_buffer_size", "spp_schur_form", "spp_schur_finish",
     "spp_schur_packed_size", "spp_schur_pack", "spp_schur_unpack",
-    "spp_assemble_analyze", "spp_assemble_get_structure", "spp_assemble_device", "spp_device_malloc",
+    "spp_assemble_analyze", "spp_assemble_get_structure", "spp_assemble_device", "spp_assemble_set_edge_weights", "spp_device_malloc",
     "spp_device_free", "spp_memcpy_h2d", "spp_memcpy_d2h", "spp_memcpy_d2d", "spp_get_phase_ms", "spp_get_dominant_kernel",
     "spp_microbench_copy", "spp_microbench_mfma_f64", "spp_microbench_ctile", "spp_microbench_update", "spp_block_ordering", "spp_set_profiling", "spp_se2_linearize_device", "spp_se2_update_device", "spp_ba_linearize_device", "spp_ba_update_device", "spp_se3_linearize_device", "spp_se3_update_device", "spp_edge_chi2_device", "spp_edge_hessian_maxdiag_device",
     "spp_lm_gain_denominator_device", "spp_dense_potrf_upper", "spp_dense_posv",
@@ -79,6 +79,7 @@ def load_library():
         "spp_assemble_analyze": (cint, [vp, i64, vp, i64, vp, vp, cint, cint, cint, i64]),
         "spp_assemble_get_structure": (cint, [vp, vp, vp, vp]),
         "spp_assemble_device": (cint, [vp, vp, vp, vp, vp, dbl, vp, vp]),
+        "spp_assemble_set_edge_weights": (cint, [vp, vp]),
         "spp_device_malloc": (cint, [vp, ctypes.c_size_t, ctypes.POINTER(vp)]),
         "spp_device_free": (cint, [vp, vp]),
         "spp_memcpy_h2d": (cint, [vp, vp, vp, ctypes.c_size_t]),
@@ -327,6 +328,10 @@ class Context:
         self._check(self.lib.spp_assemble_get_structure(self.h, _ptr(col_ptr), _ptr(row_idx), _ptr(blk_off)))
         from .blockcsc import BlockCSC
         return BlockCSC(dim, col_ptr, row_idx, blk_off, None)
+
+    def assemble_set_edge_weights(self, d_w):
+        """robust edges: device array of one weight per edge for the following assemble_device calls (None: plain edges)"""
+        return self._check(self.lib.spp_assemble_set_edge_weights(self.h, d_w))
 
     def assemble_device(self, d_J0, d_J1, d_Om, d_r, damping, d_vals, d_eta):
         return self._check(self.lib.spp_assemble_device(self.h, d_J0, d_J1, d_Om, d_r, float(damping), d_vals, d_eta))

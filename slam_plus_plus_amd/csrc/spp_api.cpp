@@ -570,6 +570,17 @@ int spp_assemble_device(spp_ctx *ctx, const double *d_J0, const double *d_J1, co
 	SPP_CATCH(ctx)
 }
 
+int spp_assemble_set_edge_weights(spp_ctx *ctx, const double *d_w)
+{
+	if(!ctx)
+		return SPP_E_BADARG;
+	SPP_TRY(ctx)
+	SPP_REQUIRE(ctx->assemble, SPP_E_STATE, "spp_assemble_set_edge_weights: call spp_assemble_analyze first");
+	assemble_set_edge_weights(ctx, d_w);
+	return SPP_OK;
+	SPP_CATCH(ctx)
+}
+
 int spp_se2_linearize_device(spp_ctx *ctx, int64_t n_edges, const int32_t *d_v0, const int32_t *d_v1,
 	const double *d_poses, const double *d_measurements, double *d_J0, double *d_J1, double *d_r)
 {

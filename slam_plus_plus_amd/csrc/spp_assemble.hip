@@ -42,6 +42,7 @@ struct AssemblePlan {
 	DevBuf<int64_t> v_base;     // [nv] scalar offset in eta
 	DevBuf<int32_t> vlist_seq[2], vlist_wave[2];
 	int64_t n_seq[2] = {0, 0}, n_wave[2] = {0, 0};
+	const double *edge_weights = nullptr; // device, one robust weight per edge, or null (assemble_set_edge_weights; not owned)
 };
 
 void assemble_release(spp_ctx *ctx)
@@ -56,6 +57,11 @@ void assemble_get_structure(const spp_ctx *ctx, int64_t *col_ptr, int64_t *row_i
 	std::copy(st.col_ptr.begin(), st.col_ptr.end(), col_ptr);
 	std::copy(st.row_idx.begin(), st.row_idx.end(), row_idx);
 	std::copy(st.blk_off.begin(), st.blk_off.end(), blk_off);
+}
+
+void assemble_set_edge_weights(spp_ctx *ctx, const double *d_w)
+{
+	ctx->assemble->edge_weights = d_w;
 }
 
 static const int SEQ_MAX_DEGREE = 24;
@@ -201,7 +207,7 @@ template <int D0, int D1, int RD>
 __global__ __launch_bounds__(256)
 void offdiag_kernel(int64_t n_ob, const int32_t *__restrict__ ob_ptr, const int32_t *__restrict__ ob_edge,
 	const int64_t *__restrict__ ob_off, const double *__restrict__ J0, const double *__restrict__ J1,
-	const double *__restrict__ Om, double *__restrict__ vals)
+	const double *__restrict__ Om, const double *__restrict__ wts, double *__restrict__ vals)
 {
 	const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if(b >= n_ob)
@@ -220,6 +226,12 @@ void offdiag_kernel(int64_t n_ob, const int32_t *__restrict__ ob_ptr, const int3
 #pragma unroll
 		for(int i = 0; i < RD * RD; ++ i) om[i] = Om[e * RD * RD + i];
 		jt_omega<D0, RD>(j0, om, T);
+		if(wts) { // robust edge: t_H0_sigma_inv = J0^T Sigma^-1 w (BaseTypes_Binary.h:771)
+			const double wgt = wts[e];
+#pragma unroll
+			for(int i = 0; i < D0 * RD; ++ i)
+				T[i] *= wgt;
+		}
 		// H01 (D0 x D1) = T J1 ; stored as is, or transposed (D1 x D0) when the ids are reversed
 #pragma unroll
 		for(int c = 0; c < D1; ++ c)
@@ -243,10 +255,18 @@ void offdiag_kernel(int64_t n_ob, const int32_t *__restrict__ ob_ptr, const int3
 // contribution of one (edge, side) to the vertex: H (D x D, upper computed, mirrored) and g (D)
 template <int D, int RD, int SIDE>
 __device__ __forceinline__ void vertex_contrib(const double *__restrict__ J, const double *__restrict__ Om,
-	const double *__restrict__ r, double *H, double *g)
+	const double *__restrict__ r, double wgt, double *H, double *g)
 {
+	// wgt: the robust weight of the edge (1 for a plain edge: the products below are then exact), applied where the
+	// reference applies it (BaseTypes_Binary.h:768-848): side 0 through T = J0^T Omega w -- H00 carries it once, g0 = T r w
+	// TWICE --, side 1 on the finished H11 and g1
 	double T[D * RD];
 	jt_omega<D, RD>(J, Om, T);
+	if(SIDE == 0) {
+#pragma unroll
+		for(int i = 0; i < D * RD; ++ i)
+			T[i] *= wgt;
+	}
 #pragma unroll
 	for(int c = 0; c < D; ++ c)
 #pragma unroll
@@ -255,7 +275,7 @@ __device__ __forceinline__ void vertex_contrib(const double *__restrict__ J, con
 #pragma unroll
 			for(int l = 0; l < RD; ++ l)
 				s += T[i + l * D] * J[l + c * RD];
-			H[i + c * D] = s;
+			H[i + c * D] = (SIDE == 0) ? s : s * wgt;
 		}
 	if(SIDE == 0) { // g0 = (J0^T Omega) r
 #pragma unroll
@@ -264,7 +284,7 @@ __device__ __forceinline__ void vertex_contrib(const double *__restrict__ J, con
 #pragma unroll
 			for(int l = 0; l < RD; ++ l)
 				s += T[i + l * D] * r[l];
-			g[i] = s;
+			g[i] = s * wgt;
 		}
 	} else {        // g1 = J1^T (Omega r)
 		double orr[RD];
@@ -282,7 +302,7 @@ __device__ __forceinline__ void vertex_contrib(const double *__restrict__ J, con
 #pragma unroll
 			for(int l = 0; l < RD; ++ l)
 				s += J[l + i * RD] * orr[l];
-			g[i] = s;
+			g[i] = s * wgt;
 		}
 	}
 }
@@ -290,10 +310,11 @@ __device__ __forceinline__ void vertex_contrib(const double *__restrict__ J, con
 // D = width of the vertices handled; when D0 == D1 a vertex may sit on either side of its edges
 template <int D, int D0, int D1, int RD>
 __device__ __forceinline__ void load_contrib(int32_t entry, const double *__restrict__ J0, const double *__restrict__ J1,
-	const double *__restrict__ Om, const double *__restrict__ r, double *H, double *g)
+	const double *__restrict__ Om, const double *__restrict__ r, const double *__restrict__ wts, double *H, double *g)
 {
 	const int64_t e = entry >> 1;
 	const int side = entry & 1;
+	const double wgt = wts ? wts[e] : 1.0;
 	double om[RD * RD], rr[RD], j[RD * D];
 #pragma unroll
 	for(int i = 0; i < RD * RD; ++ i) om[i] = Om[e * RD * RD + i];
@@ -303,13 +324,13 @@ __device__ __forceinline__ void load_contrib(int32_t entry, const double *__rest
 		if(D == D0) {
 #pragma unroll
 			for(int i = 0; i < RD * D; ++ i) j[i] = J0[e * RD * D0 + i];
-			vertex_contrib<D, RD, 0>(j, om, rr, H, g);
+			vertex_contrib<D, RD, 0>(j, om, rr, wgt, H, g);
 		}
 	} else {
 		if(D == D1) {
 #pragma unroll
 			for(int i = 0; i < RD * D; ++ i) j[i] = J1[e * RD * D1 + i];
-			vertex_contrib<D, RD, 1>(j, om, rr, H, g);
+			vertex_contrib<D, RD, 1>(j, om, rr, wgt, H, g);
 		}
 	}
 }
@@ -341,7 +362,8 @@ __global__ __launch_bounds__(256)
 void vertex_seq_kernel(int64_t nlist, const int32_t *__restrict__ vlist, const int32_t *__restrict__ vl_ptr,
 	const int32_t *__restrict__ vl_entry, const int64_t *__restrict__ v_doff, const int64_t *__restrict__ v_base,
 	const double *__restrict__ J0, const double *__restrict__ J1, const double *__restrict__ Om,
-	const double *__restrict__ r, int64_t unary_vertex, double damping, double *__restrict__ vals, double *__restrict__ eta)
+	const double *__restrict__ r, const double *__restrict__ wts, int64_t unary_vertex, double damping, double *__restrict__ vals,
+	double *__restrict__ eta)
 {
 	const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if(t >= nlist)
@@ -355,7 +377,7 @@ void vertex_seq_kernel(int64_t nlist, const int32_t *__restrict__ vlist, const i
 	bool first = true;
 	for(int32_t q = vl_ptr[v]; q < vl_ptr[v + 1]; ++ q) {
 		double Hc[D * D], gc[D];
-		load_contrib<D, D0, D1, RD>(vl_entry[q], J0, J1, Om, r, Hc, gc);
+		load_contrib<D, D0, D1, RD>(vl_entry[q], J0, J1, Om, r, wts, Hc, gc);
 		if(first) { // the first source is assigned, the others are added (_Lambda_Base.h:598-604)
 #pragma unroll
 			for(int c = 0; c < D; ++ c)
@@ -381,7 +403,8 @@ __global__ __launch_bounds__(256)
 void vertex_wave_kernel(int64_t nlist, const int32_t *__restrict__ vlist, const int32_t *__restrict__ vl_ptr,
 	const int32_t *__restrict__ vl_entry, const int64_t *__restrict__ v_doff, const int64_t *__restrict__ v_base,
 	const double *__restrict__ J0, const double *__restrict__ J1, const double *__restrict__ Om,
-	const double *__restrict__ r, int64_t unary_vertex, double damping, double *__restrict__ vals, double *__restrict__ eta)
+	const double *__restrict__ r, const double *__restrict__ wts, int64_t unary_vertex, double damping, double *__restrict__ vals,
+	double *__restrict__ eta)
 {
 	const int64_t t = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
 	const int lane = threadIdx.x & 63;
@@ -395,7 +418,7 @@ void vertex_wave_kernel(int64_t nlist, const int32_t *__restrict__ vlist, const 
 	for(int i = 0; i < D; ++ i) g[i] = 0;
 	for(int32_t q = vl_ptr[v] + lane; q < vl_ptr[v + 1]; q += 64) {
 		double Hc[D * D], gc[D];
-		load_contrib<D, D0, D1, RD>(vl_entry[q], J0, J1, Om, r, Hc, gc);
+		load_contrib<D, D0, D1, RD>(vl_entry[q], J0, J1, Om, r, wts, Hc, gc);
 #pragma unroll
 		for(int c = 0; c < D; ++ c)
 #pragma unroll
@@ -433,16 +456,16 @@ static void assemble_t(spp_ctx *ctx, const double *J0, const double *J1, const d
 	hipStream_t s = ctx->stream;
 	if(ap->n_ob)
 		hipLaunchKernelGGL((offdiag_kernel<D0, D1, RD>), dim3((unsigned)((ap->n_ob + 255) / 256)), dim3(256), 0, s,
-			ap->n_ob, ap->ob_ptr.p, ap->ob_edge.p, ap->ob_off.p, J0, J1, Om, vals);
+			ap->n_ob, ap->ob_ptr.p, ap->ob_edge.p, ap->ob_off.p, J0, J1, Om, ap->edge_weights, vals);
 #define SPP_VERTEX_LAUNCH(D, cls) \
 	if(ap->n_seq[cls]) \
 		hipLaunchKernelGGL((vertex_seq_kernel<D, D0, D1, RD>), dim3((unsigned)((ap->n_seq[cls] + 255) / 256)), dim3(256), 0, s, \
 			ap->n_seq[cls], ap->vlist_seq[cls].p, ap->vl_ptr.p, ap->vl_entry.p, ap->v_doff.p, ap->v_base.p, \
-			J0, J1, Om, r, ap->unary_vertex, damping, vals, eta); \
+			J0, J1, Om, r, ap->edge_weights, ap->unary_vertex, damping, vals, eta); \
 	if(ap->n_wave[cls]) \
 		hipLaunchKernelGGL((vertex_wave_kernel<D, D0, D1, RD>), dim3((unsigned)((ap->n_wave[cls] + 3) / 4)), dim3(256), 0, s, \
 			ap->n_wave[cls], ap->vlist_wave[cls].p, ap->vl_ptr.p, ap->vl_entry.p, ap->v_doff.p, ap->v_base.p, \
-			J0, J1, Om, r, ap->unary_vertex, damping, vals, eta);
+			J0, J1, Om, r, ap->edge_weights, ap->unary_vertex, damping, vals, eta);
 	SPP_VERTEX_LAUNCH(D0, 0)
 	if(D0 != D1) {
 		SPP_VERTEX_LAUNCH(D1, 1)

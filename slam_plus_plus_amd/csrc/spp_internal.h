@@ -274,6 +274,7 @@ void assemble_analyze(spp_ctx *ctx, int64_t nv, const int32_t *dim, int64_t ne, 
 	const int64_t *v1, int d0, int d1, int rd, int64_t unary_vertex);
 void assemble_run(spp_ctx *ctx, const double *J0, const double *J1, const double *Om, const double *r,
 	double damping, double *vals, double *eta);
+void assemble_set_edge_weights(spp_ctx *ctx, const double *d_w); // null: plain edges
 void assemble_release(spp_ctx *ctx);
 void assemble_get_structure(const spp_ctx *ctx, int64_t *col_ptr, int64_t *row_idx, int64_t *blk_off);
 

@@ -9,7 +9,10 @@ CPU part: oracle/spp_oracle.c (orc_edge_hessians / orc_reduce) against the fixtu
 GPU part (-m gpu): the HIP assembly kernels (csrc/spp_assemble.hip) against the same fixtures through the C ABI.
 The BA graph interleaves camera and point ids: about half of its camera-point blocks are stored transposed
 (BaseTypes_Binary.h:783-806); its second record carries the Levenberg-Marquardt damping on the diagonal
-(NonlinearSolver_Lambda_LM.h:228-239)."""
+(NonlinearSolver_Lambda_LM.h:228-239).
+ba_robust_lambda.npz: the same BA problem with ROBUST edges -- the reference's CBaseEdge::Robust option with its Huber
+kernel (include/slam/RobustUtils.h), per-edge weights in `w` -- and the Lambda / eta of the reference's robust assembly
+branch (BaseTypes_Binary.h:768-848: the weight once on every Hessian block, TWICE on the first vertex's right-hand side)."""
 import os
 
 import numpy as np
@@ -77,6 +80,36 @@ def test_oracle_damped_assembly_matches_the_reference_lm_lambda():
     lam, eta = orc.assemble(prob, damping=alpha)
     _check(lam, eta, g, "_lm")
     assert np.array_equal(g["eta_lm"], g["eta"])  # same state: damping does not touch eta
+
+
+def test_oracle_robust_assembly_matches_the_reference_lambda():
+    g, prob = _load("ba_robust")
+    w = g["w"]
+    assert np.count_nonzero(w < 1.0) > w.size // 3 and w.min() > 0 and w.max() == 1.0  # the kernel really bites
+    lam, eta = orc.assemble(prob, weights=w)
+    _check(lam, eta, g)
+    lam0, eta0 = orc.assemble(prob)  # ... and the plain assembly is NOT what the fixture holds
+    assert np.abs(lam0.vals - g["vals"]).max() > 1e-3 * np.abs(g["vals"]).max()
+
+
+@pytest.mark.gpu
+def test_hip_robust_assembly_matches_the_reference_lambda(hip_ctx):
+    from slam_plus_plus_amd import api
+    g, prob = _load("ba_robust")
+    st = hip_ctx.assemble_analyze(prob.dim, prob.v0, prob.v1, prob.d0, prob.d1, prob.rd, prob.unary_vertex)
+    arrs = [api.DeviceArray.from_host(hip_ctx, np.ascontiguousarray(a, dtype=np.float64).ravel())
+            for a in (prob.J0, prob.J1, prob.Om, prob.r, g["w"])]
+    dv = api.DeviceArray(hip_ctx, st.nvals)
+    de = api.DeviceArray(hip_ctx, st.n)
+    hip_ctx.assemble_set_edge_weights(arrs[4].ptr)
+    hip_ctx.assemble_device(*[a.ptr for a in arrs[:4]], 0.0, dv.ptr, de.ptr)
+    _check(st.with_vals(dv.download()), de.download(), g)
+    hip_ctx.assemble_set_edge_weights(None)  # back to plain edges: the plain fixture of the same problem
+    hip_ctx.assemble_device(*[a.ptr for a in arrs[:4]], 0.0, dv.ptr, de.ptr)
+    g0, _ = _load("ba")
+    _check(st.with_vals(dv.download()), de.download(), g0)
+    for d in arrs + [dv, de]:
+        d.free()
 
 
 @pytest.mark.gpu
