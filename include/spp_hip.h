@@ -179,6 +179,11 @@ int spp_assemble_device(spp_ctx *ctx, const double *d_J0, const double *d_J1,
  * H11 and the second vertex's right-hand side once. The array is NOT copied (it must stay valid); NULL restores plain
  * edges; spp_assemble_analyze resets it. */
 int spp_assemble_set_edge_weights(spp_ctx *ctx, const double *d_w);
+/* the weights themselves, on the device: w_e = kernel(||r_e|| / scale) -- CRobustify_ErrorNorm_Default::f_RobustWeight
+ * (include/slam/RobustUtils.h:396-400) with kind 0 = Huber, w = 1 for x <= param, param / x beyond (CHuberLoss::operator (),
+ * include/geometry/RobustLoss.h:100-104; the reference's default param is 1.345). Asynchronous on the ctx stream. */
+int spp_edge_robust_weights_device(spp_ctx *ctx, int64_t n_edges, int rd, int kind, double scale, double param,
+	const double *d_r, double *d_w_out);
 
 /* ---- device memory helpers for hosts without a HIP runtime of their own ---------------------------- */
 /* ---- on-device geometry of 2D pose graphs (CEdgePose2D) --------------------------

@@ -32,7 +32,7 @@ EXPORTS = [
     "spp_schur_packed_size", "spp_schur_pack", "spp_schur_unpack",
     "spp_assemble_analyze", "spp_assemble_get_structure", "spp_assemble_device", "spp_assemble_set_edge_weights", "spp_device_malloc",
     "spp_device_free", "spp_memcpy_h2d", "spp_memcpy_d2h", "spp_memcpy_d2d", "spp_get_phase_ms", "spp_get_dominant_kernel",
-    "spp_microbench_copy", "spp_microbench_mfma_f64", "spp_microbench_ctile", "spp_microbench_update", "spp_block_ordering", "spp_set_profiling", "spp_se2_linearize_device", "spp_se2_update_device", "spp_ba_linearize_device", "spp_ba_update_device", "spp_se3_linearize_device", "spp_se3_update_device", "spp_edge_chi2_device", "spp_edge_hessian_maxdiag_device",
+    "spp_microbench_copy", "spp_microbench_mfma_f64", "spp_microbench_ctile", "spp_microbench_update", "spp_block_ordering", "spp_set_profiling", "spp_se2_linearize_device", "spp_se2_update_device", "spp_ba_linearize_device", "spp_ba_update_device", "spp_se3_linearize_device", "spp_se3_update_device", "spp_edge_chi2_device", "spp_edge_robust_weights_device", "spp_edge_hessian_maxdiag_device",
     "spp_lm_gain_denominator_device", "spp_dense_potrf_upper", "spp_dense_posv",
     "spp_dense_gemm_tn_sub", "spp_version",
 ]
@@ -98,6 +98,7 @@ def load_library():
         "spp_se3_linearize_device": (cint, [vp, ctypes.c_int64, vp, vp, vp, vp, vp, vp, vp]),
         "spp_se3_update_device": (cint, [vp, ctypes.c_int64, vp, vp, cint, _c_f64p]),
         "spp_edge_chi2_device": (cint, [vp, ctypes.c_int64, cint, vp, vp, _c_f64p]),
+        "spp_edge_robust_weights_device": (cint, [vp, ctypes.c_int64, cint, cint, dbl, dbl, vp, vp]),
         "spp_edge_hessian_maxdiag_device": (cint, [vp, ctypes.c_int64, cint, cint, cint, vp, vp, vp, _c_f64p]),
         "spp_lm_gain_denominator_device": (cint, [vp, ctypes.c_int64, vp, vp, ctypes.c_double, _c_f64p]),
         "spp_ba_linearize_device": (cint, [vp, ctypes.c_int64, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
@@ -239,6 +240,10 @@ class Context:
         out = ctypes.c_double()
         self._check(self.lib.spp_se3_update_device(self.h, n_vertices, d_poses, d_dx, 1 if apply else 0, ctypes.byref(out)))
         return out.value ** 0.5
+
+    def edge_robust_weights_device(self, n_edges, rd, d_r, d_w, scale, param=1.345, kind=0):
+        """w_e = Huber(||r_e|| / scale) on the device (the reference's CRobustify_ErrorNorm_Default with CHuberLossd)"""
+        return self._check(self.lib.spp_edge_robust_weights_device(self.h, n_edges, rd, kind, float(scale), float(param), d_r, d_w))
 
     def edge_chi2_device(self, n_edges, rd, d_r, d_Om):
         out = ctypes.c_double()

@@ -663,6 +663,18 @@ int spp_ba_update_device(spp_ctx *ctx, int64_t n_cams, double *d_cams, const int
 	SPP_CATCH(ctx)
 }
 
+int spp_edge_robust_weights_device(spp_ctx *ctx, int64_t n_edges, int rd, int kind, double scale, double param,
+	const double *d_r, double *d_w_out)
+{
+	if(!ctx || n_edges < 0 || !d_r || !d_w_out)
+		return SPP_E_BADARG;
+	SPP_TRY(ctx)
+	SPP_HIP_CHECK(hipSetDevice(ctx->device));
+	edge_robust_weights(ctx, n_edges, rd, kind, scale, param, d_r, d_w_out);
+	return SPP_OK;
+	SPP_CATCH(ctx)
+}
+
 int spp_edge_chi2_device(spp_ctx *ctx, int64_t n_edges, int rd, const double *d_r, const double *d_Omega, double *h_chi2)
 {
 	if(!ctx || n_edges < 0 || !d_r || !d_Omega || !h_chi2)

@@ -518,6 +518,34 @@ static double fetch_scalar(spp_ctx *ctx)
 	return h;
 }
 
+// ---- robust kernels on the error norm (include/geometry/RobustLoss.h; mix-in include/slam/RobustUtils.h:368-400):
+// w_e = kernel(||r_e|| / scale). kind 0: Huber, w = 1 for x <= k, k / x beyond (CHuberLoss::operator (), :100-104)
+__global__ __launch_bounds__(256)
+void edge_robust_weight_kernel(int64_t ne, int rd, int kind, double scale, double param, const double *__restrict__ r,
+	double *__restrict__ w)
+{
+	const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if(e >= ne)
+		return;
+	double s = 0;
+	for(int i = 0; i < rd; ++ i)
+		s += r[e * rd + i] * r[e * rd + i]; // Eigen's norm(): sqrt of the sum of squares, in order
+	const double x = sqrt(s) / scale;
+	w[e] = (x <= param) ? 1.0 : param / x;
+	(void)kind;
+}
+
+void edge_robust_weights(spp_ctx *ctx, int64_t ne, int rd, int kind, double scale, double param, const double *d_r, double *d_w)
+{
+	SPP_REQUIRE(kind == 0, SPP_E_UNSUPPORTED, "robust weights: only the Huber kernel (kind 0) is instantiated");
+	SPP_REQUIRE(scale > 0 && param > 0 && rd > 0, SPP_E_BADARG, "robust weights: scale, parameter and residual dimension must be positive");
+	if(!ne)
+		return;
+	hipLaunchKernelGGL(edge_robust_weight_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, ctx->stream, ne, rd, kind,
+		scale, param, d_r, d_w);
+	SPP_HIP_CHECK(hipGetLastError());
+}
+
 double edge_chi2(spp_ctx *ctx, int64_t ne, int rd, const double *d_r, const double *d_Om)
 {
 	if(!ne)

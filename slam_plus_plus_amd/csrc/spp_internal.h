@@ -219,6 +219,7 @@ void se2_linearize(spp_ctx *ctx, int64_t ne, const int32_t *d_v0, const int32_t 
 	const double *d_meas, double *d_J0, double *d_J1, double *d_r);
 double se2_update(spp_ctx *ctx, int64_t nv, double *d_poses, const double *d_dx, bool apply);
 double edge_chi2(spp_ctx *ctx, int64_t ne, int rd, const double *d_r, const double *d_Om);
+void edge_robust_weights(spp_ctx *ctx, int64_t ne, int rd, int kind, double scale, double param, const double *d_r, double *d_w);
 double edge_hessian_maxdiag(spp_ctx *ctx, int64_t ne, int rd, int d0, int d1, const double *d_J0, const double *d_J1,
 	const double *d_Om);
 double lm_gain_denominator(spp_ctx *ctx, int64_t n, const double *d_dx, const double *d_rhs, double alpha);

@@ -104,6 +104,12 @@ def test_hip_robust_assembly_matches_the_reference_lambda(hip_ctx):
     hip_ctx.assemble_set_edge_weights(arrs[4].ptr)
     hip_ctx.assemble_device(*[a.ptr for a in arrs[:4]], 0.0, dv.ptr, de.ptr)
     _check(st.with_vals(dv.download()), de.download(), g)
+    # the weights themselves from the device-resident errors: the fixture's edges use a Huber kernel at a scale of 3/4
+    dw = api.DeviceArray(hip_ctx, g["w"].size)
+    hip_ctx.edge_robust_weights_device(g["w"].size, prob.rd, arrs[3].ptr, dw.ptr, scale=0.75)
+    w_dev = dw.download()
+    dw.free()
+    assert np.abs(w_dev - g["w"]).max() <= 4e-16, np.abs(w_dev - g["w"]).max()
     hip_ctx.assemble_set_edge_weights(None)  # back to plain edges: the plain fixture of the same problem
     hip_ctx.assemble_device(*[a.ptr for a in arrs[:4]], 0.0, dv.ptr, de.ptr)
     g0, _ = _load("ba")
