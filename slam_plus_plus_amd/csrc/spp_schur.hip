@@ -225,6 +225,9 @@ constexpr int SACC_WAVES = 4; // waves per workgroup
 #ifndef SPP_SACC_RP
 #define SPP_SACC_RP 64 // pairs per round
 #endif
+#ifndef SPP_SACC_UCOL
+#define SPP_SACC_UCOL 0
+#endif
 #ifndef SPP_SACC_GLDS
 #define SPP_SACC_GLDS 1 // 1: the gathered blocks go from L2 / HBM straight into the LDS images (global_load_lds_dwordx4)
 #endif
@@ -385,6 +388,28 @@ void s_accum_kernel(const SaccItem *__restrict__ items, const int32_t *__restric
 		__builtin_amdgcn_wave_barrier();
 		// ---- every lane: its own pair out of LDS
 		if(mine) {
+#if SPP_SACC_UCOL
+			// U column by column (DL values live at a time instead of the whole block): the register budget of three waves per SIMD
+			double w[BLK];
+#pragma unroll
+			for(int e = 0; e < BLK; ++ e)
+				w[e] = sw[lane * ST + e];
+#pragma unroll
+			for(int c = 0; c < DP; ++ c) {
+				double uc[DL];
+#pragma unroll
+				for(int t = 0; t < DL; ++ t)
+					uc[t] = su[lane * ST + c + DP * t];
+#pragma unroll
+				for(int r = 0; r < DP; ++ r) {
+					double sp = 0;
+#pragma unroll
+					for(int t = 0; t < DL; ++ t)
+						sp += w[r + DP * t] * uc[t];
+					acc[r + DP * c] += sp;
+				}
+			}
+#else
 			double w[BLK], u[BLK];
 #pragma unroll
 			for(int e = 0; e < BLK; ++ e) {
@@ -401,6 +426,7 @@ void s_accum_kernel(const SaccItem *__restrict__ items, const int32_t *__restric
 						sp += w[r + DP * t] * u[c + DP * t];
 					acc[r + DP * c] += sp;
 				}
+#endif
 		}
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 		__builtin_amdgcn_wave_barrier();
@@ -412,9 +438,11 @@ void s_accum_kernel(const SaccItem *__restrict__ items, const int32_t *__restric
 			// adds elements 2 e2, 2 e2 + 1 of the q-th segment of the partial list in list order; the NSEG segment
 			// sums are then added in order: a fixed summation order (bit-reproducible), with a dependent chain a
 			// third as long as one lane walking the whole list.
+			if(lane < RP) { // (the image holds RP rows; lanes beyond own no pair and hold zeros)
 #pragma unroll
-			for(int e = 0; e < NE; ++ e)
-				rw[lane * RS + e] = acc[e];
+				for(int e = 0; e < NE; ++ e)
+					rw[lane * RS + e] = acc[e];
+			}
 			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 			__builtin_amdgcn_wave_barrier();
 			const int seg_len = (nact + NSEG - 1) / NSEG;
