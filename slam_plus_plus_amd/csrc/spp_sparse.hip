@@ -89,6 +89,10 @@ struct SparsePlan {
 	DevBuf<int64_t> front_tinv;                // [ns] offset of a big front's diagonal-block inverses
 	DevBuf<double> team_tinv;
 	int32_t dag_first1 = 0;                    // position in dag_list of the first front of level 1
+	// the levels below the first front of more than 64 rows go as a launch of their own with 256 threads and the LDS of
+	// their own classes: four workgroups per CU instead of one (the wide bottom of a large tree)
+	int32_t dag_split = 0, dag_split_level = 0;
+	size_t dag_lds_low = 0;
 	int dag_epoch = 0;
 	size_t dag_lds = 0;                        // dynamic LDS of the factorization launch (largest class present)
 	bool dag_ok = true;                        // false after a timed-out wait: level-by-level launches from then on
@@ -554,6 +558,21 @@ void sparse_analyze(spp_ctx *ctx, const Structure &st)
 			++ sp->dag_first1;
 		sp->dag_n = (int32_t)dag_list.size();
 		sp->dag_n_bwd = (int32_t)dag_list_bwd.size();
+		{
+			int32_t l1 = limit;
+			for(size_t i = 0; i < fronts_in.size(); ++ i)
+				if(front_cls[fronts_in[i]] >= 2)
+					l1 = std::min(l1, level[fronts_in[i]]);
+			sp->dag_split_level = l1;
+			sp->dag_split = 0;
+			int low_cls = 0;
+			while(sp->dag_split < (int32_t)dag_list.size() && level[dag_list[sp->dag_split]] < l1) {
+				low_cls = std::max(low_cls, front_cls[dag_list[sp->dag_split]]);
+				++ sp->dag_split;
+			}
+			const size_t hpl = low_cls == 0 ? 32 : 64;
+			sp->dag_lds_low = (hpl * (hpl + 1) + hpl + 2 * 16 * PT + 8) * sizeof(double);
+		}
 		const size_t hp = max_cls == 0 ? 32 : (max_cls == 1 ? 64 : (max_cls == 2 ? 128 : MID_FRONT_MAX));
 		size_t lds_doubles = (max_cls >= 3 ? std::max<size_t>((size_t)17 * MID_FRONT_MAX + MID_FRONT_MAX, (size_t)128 * 129 + 128) : hp * (hp + 1) + hp)
 			+ 2 * 16 * PT + 8;
@@ -1424,9 +1443,11 @@ void front_dag_kernel(DagArgs da, FrontArgs fa)
 			if(tid == 0) {
 				if(da.trace)
 					da.trace[8 * blockIdx.x + 1] = wall_clock64();
-				for(int cq = fa.child_ptr[s]; cq < fa.child_ptr[s + 1]; ++ cq)
-					if(!dag_wait(da.done + fa.child_list[cq], da.epoch, da.abort, da.timeout_ticks))
+				for(int cq = fa.child_ptr[s]; cq < fa.child_ptr[s + 1]; ++ cq) {
+					const int c = fa.child_list[cq];
+					if(da.front_level[c] >= da.level_first && !dag_wait(da.done + c, da.epoch, da.abort, da.timeout_ticks))
 						break;
+				}
 				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 				if(da.trace)
@@ -1662,10 +1683,23 @@ static void sparse_enqueue(spp_ctx *ctx, const double *d_vals, double *d_rhs)
 			SPP_HIP_CHECK(hipMemsetAsync(trace_buf.p, 0, (size_t)8 * sp->dag_n * sizeof(long long), s));
 			da.trace = trace_buf.p;
 		}
+		static int split_env = -1;
+		if(split_env < 0)
+			split_env = getenv("SPP_DAG_SPLIT") ? atoi(getenv("SPP_DAG_SPLIT")) : 1;
 		if(sp->dag_n > skip) {
 			FrontArgs fa = make_front_args(ctx, sp, d_vals);
 			fa.trace = da.trace;
-			hipLaunchKernelGGL(front_dag_kernel, dim3((unsigned)(sp->dag_n - skip)), dim3(DAG_THREADS), sp->dag_lds, s, da, fa);
+			if(split_env && !da.trace && sp->dag_split >= (split_env >= 2 ? 1 : 1024) && sp->dag_split < sp->dag_n) { // (SPP_DAG_SPLIT=2: whatever the size)
+				// the bottom of the tree (fronts of at most 64 rows): 256 threads and their own LDS, four workgroups per CU;
+				// the launch above it skips the waits for those children (finished by the kernel boundary)
+				hipLaunchKernelGGL(front_dag_kernel, dim3((unsigned)sp->dag_split), dim3(256), sp->dag_lds_low, s, da, fa);
+				DagArgs db = da;
+				db.list = sp->dag_list.p + sp->dag_split;
+				db.rank = sp->dag_rank.p + sp->dag_split;
+				db.level_first = sp->dag_split_level;
+				hipLaunchKernelGGL(front_dag_kernel, dim3((unsigned)(sp->dag_n - sp->dag_split)), dim3(DAG_THREADS), sp->dag_lds, s, db, fa);
+			} else
+				hipLaunchKernelGGL(front_dag_kernel, dim3((unsigned)(sp->dag_n - skip)), dim3(DAG_THREADS), sp->dag_lds, s, da, fa);
 		}
 		if(trace_left > 0 && -- trace_left == 0) { // debugging: per level, when its fronts started / had their children / ended (us)
 			std::vector<long long> tr((size_t)8 * sp->dag_n);
