@@ -5,6 +5,8 @@ big fronts by teams of workgroups. Fallbacks, selected by environment variables 
 (hence one child process per variant, started before this process's own GPU work matters to it):
     SPP_SPARSE_TEAMS=0   big fronts and everything above them level by level through the host-driven dense factor
     SPP_SPARSE_DAG=0     one launch per level and size class (the round-1 schedule, also taken after a timed-out flag wait)
+    SPP_DAG_SPLIT=2      the bottom of the tree (fronts of at most 64 rows) as a launch of its own with small workgroups --
+                         taken by itself only from 1024 such fronts on
 Every variant must reproduce the default's solution of the sphere2500-shaped system (big fronts up to 655 rows, 14 levels)
 to the rounding of a different summation order, and each must be bit-reproducible run to run."""
 import os
@@ -48,7 +50,9 @@ def test_fallback_schedules_match_the_dependency_driven_one(tmp_path):
     x_dag = _run(tmp_path, "dag", {})
     x_noteam = _run(tmp_path, "noteam", {"SPP_SPARSE_TEAMS": "0"})
     x_levels = _run(tmp_path, "levels", {"SPP_SPARSE_DAG": "0"})
+    x_split = _run(tmp_path, "split", {"SPP_DAG_SPLIT": "2"})
     n = np.linalg.norm(x_dag)
     # cond ~1e11 on this undamped pose graph: solutions of different (equally valid) summation orders differ by ~cond * eps
     assert np.linalg.norm(x_noteam - x_dag) / n < 1e-6
     assert np.linalg.norm(x_levels - x_dag) / n < 1e-6
+    assert np.array_equal(x_split, x_dag)  # the same fronts in the same order: only the launch boundaries differ
