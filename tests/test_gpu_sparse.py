@@ -102,3 +102,19 @@ def test_not_posdef_returns_false():
     x = eta.copy()
     assert s.Solve_PosDef_Blocky(lam.with_vals(vals), x) is False
     assert np.array_equal(x, eta)
+
+
+def test_large_pose_graph_through_the_split_dependency_driven_launch():
+    """20 000 poses: 5 277 fronts over 34 levels -- twenty times the workgroups a launch holds resident, and a bottom of
+    the tree wide enough (>= 1024 fronts of at most 64 rows) to go as a launch of its own with small workgroups."""
+    prob = synth.se2_problem(20000, 12000, 77, name="se2_big")
+    lam, eta = orc.assemble(prob)
+    solver = api.CLinearSolver_HIP(mode=api.MODE_SPARSE)
+    x = eta.copy()
+    assert solver.Solve_PosDef_Blocky(lam, x)
+    assert solver.ctx.info("N_SUPERNODES") > 4000
+    res = np.linalg.norm(lam.matvec(x) - eta) / np.linalg.norm(eta)
+    assert res < 1e-11, res
+    x2 = eta.copy()
+    assert solver.Solve_PosDef_Blocky(lam, x2)
+    assert np.array_equal(x, x2), "factorization must be bit-reproducible"
