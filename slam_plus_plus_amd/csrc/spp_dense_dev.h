@@ -388,9 +388,19 @@ __device__ __forceinline__ void potrf_diag_body(double *__restrict__ Ablk, int64
 				// chain of the diagonal tile then has its matrix core to itself (7 000 -> 5 300 cycles per panel).
 				// Row block J -- final since step B -- goes back to global memory inside this phase (below): R (rows
 				// j0 .. j0+15 right of and on the diagonal) and columns j0 .. j0+15 of the inverse.
+#ifndef SPP_POTRF_SIMD0_IDLE
+#define SPP_POTRF_SIMD0_IDLE 1
+#endif
+#if SPP_POTRF_SIMD0_IDLE
 				constexpr int NCW = NW - 1 - (NW / 4 - 1);
 				const int slot = wave - 1 - (wave >> 2);
-				for(int q = ((wave & 3) ? slot + 1 : (1 << 20)); q < nR + nG; q += 2 * NCW) { // two tiles per wave and round
+				const bool takes_tiles = (wave & 3) != 0;
+#else
+				constexpr int NCW = NW - 1;
+				const int slot = wave - 1;
+				const bool takes_tiles = true;
+#endif
+				for(int q = (takes_tiles ? slot + 1 : (1 << 20)); q < nR + nG; q += 2 * NCW) { // two tiles per wave and round
 					const int q1 = q + NCW;
 					int I0, C0, I1 = 0, C1 = 0;
 					bool g0, g1 = false;

@@ -849,7 +849,7 @@ __device__ __forceinline__ void front_body(const int s, const FrontArgs &fa, dou
 	for(int J = 0; J < npan; ++ J) {
 		const int j0 = J * 16;
 		if(wave == 0)
-			diag_tile_factor_rt(TSF, T, Dv, Gd, dinv, j0, lane, fail, info, 0);
+			diag_tile_factor_sel(TSF, T, Dv, Gd, dinv, j0, lane, fail, info, 0);
 		__syncthreads();
 		if(*fail)
 			return;

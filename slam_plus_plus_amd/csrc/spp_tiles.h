@@ -266,6 +266,140 @@ __device__ __forceinline__ void diag_tile_factor_rt(const int TS, double *T, dou
 }
 
 
+// --------------------------------------------------------------------------------------------------
+// The same elimination on the vector ALU with DPP row broadcasts (gfx90a+: row_newbcast, the one DPP
+// control that 64-bit operations accept). Lane c of every 16-lane row holds the WHOLE column c of the
+// symmetric tile, A[i] = W[i][c] (32 VGPRs; the four rows of 16 lanes compute redundantly, which costs
+// nothing: an instruction takes the same cycles for 16 active lanes as for 64). The rank-1 update of pivot j,
+//     W[i][c] -= (W[j][i] / p_j) W[j][c]      rows i > j, columns c != j,
+// is ONE v_fmac_f64_dpp per row i: the multiplier -W[j][i] / p_j is lane i's entry of the scaled pivot row
+// s = -A[j] / p_j, fetched by row_newbcast:i, the other factor is the lane's own A[j] (AND-masked to zero in
+// lane j, which keeps column j out of its own pivot exactly as in the MFMA formulation above, so that rows
+// i > c of column c evolve into column c of G). The rows are independent of each other: 15 - j instructions
+// of 4..8 cycles instead of one dependent v_mfma_f64_16x16x4 (~105 cycles) plus ~140 cycles of operand set-up,
+// and no SGPR-writing v_readlane in the shadow of an MFMA. The next pivot is formed ahead of the update from
+// two broadcast scalars with the very fma the update applies to W[j+1][j+1], so its reciprocal
+// (v_rcp_f64 + one Newton step) runs beside the row updates. Same outputs, same algebra, different rounding
+// order inside a row only through fma contraction (none: every update is one fma in both forms).
+// Hazard: a DPP source written by the preceding VALU instruction needs two wait states; the compiler pads
+// nothing inside an asm statement, so the first update of a pivot carries its own s_nop 1.
+template <int L>
+__device__ __forceinline__ double row_bcast_f64(double v)
+{
+	return __builtin_amdgcn_update_dpp(v, v, 0x150 + L, 0xf, 0xf, false); // v_mov_b64_dpp row_newbcast:L (every lane is written: no separate `old`)
+}
+
+template <int I, int NOP>
+__device__ __forceinline__ void fmac_row_bcast(double &a, const double s, const double b)
+{
+	if(NOP)
+		asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+			: "+v"(a) : "v"(s), "v"(b), "n"(I));
+	else
+		asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+			: "+v"(a) : "v"(s), "v"(b), "n"(I));
+}
+
+template <int J, int I>
+struct DiagRowUpdate {
+	static __device__ __forceinline__ void run(double (&A)[16], const double s, const double b)
+	{
+		fmac_row_bcast<I, (I == J + 1)>(A[I], s, b);
+		DiagRowUpdate<J, I + 1>::run(A, s, b);
+	}
+};
+template <int J>
+struct DiagRowUpdate<J, 16> {
+	static __device__ __forceinline__ void run(double (&)[16], const double, const double) {}
+};
+
+template <int J>
+struct DiagPivot {
+	static __device__ __forceinline__ void run(double (&A)[16], double &pinv, double &pc, const unsigned nmask, const int c)
+	{
+		[[maybe_unused]] const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); // (stamps only)
+		const double rowj = A[J];
+		const double s = -rowj * pinv;                     // lane c: -W[j][c] / p_j
+		const double bj = and_f64(rowj, sbit(nmask, J));   // W[j][c], zero in lane j
+		// scalars of the next pivot, before this pivot's update: W[j][j+1] and W[j+1][j+1] live in lane j+1
+		const double wj = row_bcast_f64<J + 1>(rowj);
+		const double wd = row_bcast_f64<J + 1>(A[J + 1]);
+		DiagRowUpdate<J, J + 1>::run(A, s, bj);
+		// rounded exactly like the update of W[j+1][j+1] itself: fma(-(W[j][j+1] p_j^-1), W[j][j+1], W[j+1][j+1])
+		const double p = __builtin_fma(-wj * pinv, wj, wd);
+		const double r0 = __builtin_amdgcn_rcp(p);
+		pinv = r0 * (2.0 - p * r0);
+		pc = (c == J + 1) ? p : pc; // lane j+1 keeps its pivot
+		SPP_PIVOT_STAMP(J, p);
+		DiagPivot<J + 1>::run(A, pinv, pc, nmask, c);
+	}
+};
+template <>
+struct DiagPivot<15> {
+	static __device__ __forceinline__ void run(double (&)[16], double &, double &, const unsigned, const int) {}
+};
+
+__device__ __forceinline__ void diag_tile_factor_dpp_rt(const int TS, double *T, double *Dv, double *Gd, double *dinv, int j0,
+	int lane, int *fail, int *info, int64_t k0)
+{
+	const int c = lane & 15, q = lane >> 4;
+	SPP_TILE_STAMP(0, 0.0);
+	double A[16];
+#pragma unroll
+	for(int i = 0; i < 16; ++ i)
+		A[i] = T[(i <= c) ? (j0 + i) + (j0 + c) * TS : (j0 + c) + (j0 + i) * TS];
+	const unsigned nmask = ~(1u << c);
+	double pc = row_bcast_f64<0>(A[0]); // p_0 in every lane; lane c ends up with p_c
+	SPP_TILE_STAMP(1, pc);
+	double r0 = __builtin_amdgcn_rcp(pc);
+	double pinv = r0 * (2.0 - pc * r0); // v_rcp_f64 + one Newton step
+	DiagPivot<0>::run(A, pinv, pc, nmask, c);
+	SPP_TILE_STAMP(2, A[15] + pc);
+	// Eigen's LLT test (non-positive or NaN pivot) on the pivots themselves (the lanes of the first row of 16);
+	// the first failing column is exact because the pivots before it do not depend on it
+	{
+		const unsigned long long bl = __builtin_amdgcn_ballot_w64(q == 0 && !(pc > 0));
+		if(bl) {
+			if(lane == 0) {
+				*fail = 1;
+				info[0] = (int)(k0 + j0 + __builtin_ctzll(bl) + 1);
+			}
+			return;
+		}
+	}
+	const double sq = sqrt(pc); // R_cc
+	if(q == 0)
+		dinv[j0 + c] = 1.0 / sq;
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	const double pvc = dinv[j0 + c];
+	SPP_TILE_STAMP(3, pvc);
+	const double g = -pvc * pvc; // -1 / p_c: the deferred scale of column c of G
+	// the four rows of 16 lanes share the write-back: lane (q, c) finishes rows i = q + 4 r
+#pragma unroll
+	for(int r = 0; r < 4; ++ r) {
+		const int i = q + 4 * r;
+		// (the values are pinned in registers first: a select between two array elements is otherwise turned into an
+		// indexed load and the whole column goes through scratch memory)
+		double x0 = A[4 * r], x1 = A[4 * r + 1], x2 = A[4 * r + 2], x3 = A[4 * r + 3];
+		asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+		const double a01 = (q & 1) ? x1 : x0, a23 = (q & 1) ? x3 : x2;
+		const double a = (q & 2) ? a23 : a01;
+		const double pvi = dinv[j0 + i];
+		// i < c: R[i][c] = w / sqrt(p_i);  i > c: G[i][c] = (-w / p_c) / sqrt(p_i) = Dinv[c][i]
+		const double w = (i == c) ? pvc : a * pvi * ((i > c) ? g : 1.0);
+		T[(j0 + i) + (j0 + c) * TS] = (i == c) ? sq : w;
+		const double d = (i < c) ? 0.0 : w;
+		Dv[c + i * PT] = d;   // Dinv[c][i] (upper triangular, zero for c > i)
+		Gd[i + c * PT] = d;   // G[i][c]   (lower triangular incl. the diagonal)
+	}
+	SPP_TILE_STAMP(4, 0.0);
+}
+
+#ifndef SPP_DIAG_DPP
+#define SPP_DIAG_DPP 1 // 0: the MFMA formulation (diag_tile_factor_rt above), kept for A/B timing
+#endif
+
 template <int TS>
 __device__ __forceinline__ void tile_atb2(const double *a0, const double *b0, int b0ks, int b0js,
 	const double *a1, const double *b1, int b1ks, int b1js, int lane, v4f64 &d0, v4f64 &d1)
@@ -273,11 +407,22 @@ __device__ __forceinline__ void tile_atb2(const double *a0, const double *b0, in
 	tile_atb2_rt(TS, a0, b0, b0ks, b0js, a1, b1, b1ks, b1js, lane, d0, d1);
 }
 
+// the form in use (TS: run-time or compile-time LDS stride of the image)
+__device__ __forceinline__ void diag_tile_factor_sel(const int TS, double *T, double *Dv, double *Gd, double *dinv, int j0,
+	int lane, int *fail, int *info, int64_t k0)
+{
+#if SPP_DIAG_DPP
+	diag_tile_factor_dpp_rt(TS, T, Dv, Gd, dinv, j0, lane, fail, info, k0);
+#else
+	diag_tile_factor_rt(TS, T, Dv, Gd, dinv, j0, lane, fail, info, k0);
+#endif
+}
+
 template <int TS>
 __device__ __forceinline__ void diag_tile_factor(double *T, double *Dv, double *Gd, double *dinv, int j0,
 	int lane, int *fail, int *info, int64_t k0)
 {
-	diag_tile_factor_rt(TS, T, Dv, Gd, dinv, j0, lane, fail, info, k0);
+	diag_tile_factor_sel(TS, T, Dv, Gd, dinv, j0, lane, fail, info, k0);
 }
 
 } // namespace spp

@@ -11,6 +11,7 @@ __device__ long long g_stamp[16], g_piv[16];
 	__builtin_amdgcn_sched_barrier(0); if(lane == 0) g_stamp[k] = t_; } while(0)
 #include "../slam_plus_plus_amd/csrc/spp_tiles.h"
 #include <stdio.h>
+#include <math.h>
 #include <vector>
 #include <random>
 
@@ -22,7 +23,7 @@ __global__ __launch_bounds__(64) void k(double *Tg, int *info)
 	__syncthreads();
 	spp::diag_tile_factor<17>(T, Dv, Gd, dinv, 0, threadIdx.x, &fail, info, 0);
 	__syncthreads();
-	for(int e = threadIdx.x; e < 16 * 17; e += 64) Tg[e] = T[e] + Dv[e] + Gd[e];
+	for(int e = threadIdx.x; e < 16 * 17; e += 64) { Tg[e] = T[e]; Tg[16 * 17 + e] = Dv[e]; Tg[2 * 16 * 17 + e] = Gd[e]; }
 }
 
 int main()
@@ -39,11 +40,41 @@ int main()
 			A[i + j * 17] = s / n + (i == j ? 2.0 : 0.0);
 		}
 	double *dA; int *dI;
-	(void)hipMalloc(&dA, 16 * 17 * 8); (void)hipMalloc(&dI, 16);
+	(void)hipMalloc(&dA, 3 * 16 * 17 * 8); (void)hipMalloc(&dI, 16);
 	for(int it = 0; it < 3; ++ it) {
 		(void)hipMemcpy(dA, A.data(), 16 * 17 * 8, hipMemcpyHostToDevice);
 		hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, dA, dI);
 		(void)hipDeviceSynchronize();
+	}
+	{
+		// check against a host factorization: T upper = R, T strictly lower = G = (R^-1)^T, Dv[c + i*17] = Gd[i + c*17] = Rinv[c][i] (i >= c)
+		std::vector<double> out(3 * 16 * 17), R(n * n, 0.0), Ri(n * n, 0.0);
+		(void)hipMemcpy(out.data(), dA, 3 * 16 * 17 * 8, hipMemcpyDeviceToHost);
+		for(int j = 0; j < n; ++ j) { // R^T R = A, R upper, R(i, j) at R[i + j * n]
+			for(int i = 0; i <= j; ++ i) {
+				double s = A[i + j * 17];
+				for(int kk = 0; kk < i; ++ kk) s -= R[kk + i * n] * R[kk + j * n];
+				R[i + j * n] = (i == j) ? sqrt(s) : s / R[i + i * n];
+			}
+		}
+		for(int j = 0; j < n; ++ j) { // Ri = R^-1 (upper): back substitution per unit vector
+			for(int i = j; i >= 0; -- i) {
+				double s = (i == j) ? 1.0 : 0.0;
+				for(int kk = i + 1; kk <= j; ++ kk) s -= R[i + kk * n] * Ri[kk + j * n];
+				Ri[i + j * n] = s / R[i + i * n];
+			}
+		}
+		double eR = 0, eG = 0, eD = 0, eGd = 0;
+		for(int cc = 0; cc < n; ++ cc)
+			for(int i = 0; i < n; ++ i) {
+				const double t = out[i + cc * 17];
+				if(i <= cc) eR = fmax(eR, fabs(t - R[i + cc * n]));
+				else eG = fmax(eG, fabs(t - Ri[cc + i * n])); // G[i][c] = Rinv[c][i]
+				const double want = (i >= cc) ? Ri[cc + i * n] : 0.0;
+				eD = fmax(eD, fabs(out[16 * 17 + cc + i * 17] - want));
+				eGd = fmax(eGd, fabs(out[2 * 16 * 17 + i + cc * 17] - want));
+			}
+		printf("max abs err: R %.2e  G %.2e  Dinv %.2e  Gd %.2e\n", eR, eG, eD, eGd);
 	}
 	long long t[16];
 	(void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_stamp), sizeof(t));
