@@ -127,6 +127,16 @@ int spp_get_ordering(const spp_ctx *ctx, int64_t *h_order);
 #define SPP_ORDER_ND  1
 int spp_block_ordering(int64_t nb, const int64_t *col_ptr, const int64_t *row_idx, int method, int64_t *h_order);
 
+/* The symbolic Schur plan of an upper block pattern, host only (no context, no GPU): what the reference recomputes
+ * structurally in every CLinearSolver_Schur::Solve_PosDef_Blocky call (guided ordering LinearSolver_Schur.cpp:771-838,
+ * the slices LinearSolver_Schur.h:1699-1709, the symbolic part of MultiplyToWith BlockMatrixFBS.inl:1147-1304) as
+ * observation lists, the block pattern of S and its per-block lists of block products. Runs on up to 16 host threads
+ * (SPP_PLAN_THREADS); the result does not depend on their number. out[0..7] = poses, landmarks of this shard,
+ * observations, block products, blocks of S, work items, split blocks, a 64-bit checksum of the lists; *seconds = wall
+ * clock of the plan. For tests and for timing the analysis phase without a device. */
+int spp_schur_plan_host(int64_t nb, const int32_t *dim, const int64_t *col_ptr, const int64_t *row_idx, int shard_rank,
+	int shard_world, int sparse_S, int64_t *out, double *seconds);
+
 /* ---- numeric: host-pointer entry points (what the header adapter calls) ----------------------------
  * replaces: Solve_PosDef_Blocky (LinearSolver_UberBlock.h:312-426; LinearSolver_Schur.h:1623-1935)
  * and Solve_PosDef (LinearSolver_UberBlock.h:143-258). h_vals holds the blocks at the blk_off

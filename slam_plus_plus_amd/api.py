@@ -32,7 +32,7 @@ EXPORTS = [
     "spp_schur_packed_size", "spp_schur_pack", "spp_schur_unpack",
     "spp_assemble_analyze", "spp_assemble_get_structure", "spp_assemble_device", "spp_assemble_set_edge_weights", "spp_device_malloc",
     "spp_device_free", "spp_memcpy_h2d", "spp_memcpy_d2h", "spp_memcpy_d2d", "spp_get_phase_ms", "spp_get_dominant_kernel",
-    "spp_microbench_copy", "spp_microbench_mfma_f64", "spp_microbench_ctile", "spp_microbench_update", "spp_block_ordering", "spp_set_profiling", "spp_se2_linearize_device", "spp_se2_update_device", "spp_ba_linearize_device", "spp_ba_update_device", "spp_se3_linearize_device", "spp_se3_update_device", "spp_edge_chi2_device", "spp_edge_robust_weights_device", "spp_edge_hessian_maxdiag_device",
+    "spp_microbench_copy", "spp_microbench_mfma_f64", "spp_microbench_ctile", "spp_microbench_update", "spp_block_ordering", "spp_schur_plan_host", "spp_set_profiling", "spp_se2_linearize_device", "spp_se2_update_device", "spp_ba_linearize_device", "spp_ba_update_device", "spp_se3_linearize_device", "spp_se3_update_device", "spp_edge_chi2_device", "spp_edge_robust_weights_device", "spp_edge_hessian_maxdiag_device",
     "spp_lm_gain_denominator_device", "spp_dense_potrf_upper", "spp_dense_posv",
     "spp_dense_gemm_tn_sub", "spp_version",
 ]
@@ -92,6 +92,7 @@ def load_library():
         "spp_microbench_ctile": (cint, [vp, cint, cint, _c_f64p]),
         "spp_microbench_update": (cint, [vp, ctypes.c_int64, cint, _c_f64p]),
         "spp_block_ordering": (cint, [ctypes.c_int64, vp, vp, cint, vp]),
+        "spp_schur_plan_host": (cint, [ctypes.c_int64, vp, vp, vp, cint, cint, cint, vp, vp]),
         "spp_set_profiling": (cint, [vp, cint]),
         "spp_se2_linearize_device": (cint, [vp, ctypes.c_int64, vp, vp, vp, vp, vp, vp, vp]),
         "spp_se2_update_device": (cint, [vp, ctypes.c_int64, vp, vp, cint, _c_f64p]),
@@ -134,6 +135,25 @@ def block_ordering(lam, method=ORDER_AMD):
     if code != 0:
         raise SppError("spp_block_ordering failed: %d" % code)
     return out
+
+
+def schur_plan_host(lam, shard_rank=0, shard_world=1, sparse_S=False):
+    """Host-only symbolic Schur plan of a BlockCSC pattern (spp_schur_plan_host): returns a dict with the list sizes,
+    a checksum of the lists and the wall clock of the plan. No GPU needed."""
+    lib = load_library()
+    col_ptr = np.ascontiguousarray(lam.col_ptr, dtype=np.int64)
+    row_idx = np.ascontiguousarray(lam.row_idx, dtype=np.int64)
+    dim = np.ascontiguousarray(lam.dim, dtype=np.int32)
+    out = np.zeros(8, dtype=np.int64)
+    sec = ctypes.c_double(0.0)
+    code = lib.spp_schur_plan_host(lam.nb, _ptr(dim), _ptr(col_ptr), _ptr(row_idx), shard_rank, shard_world,
+                                   1 if sparse_S else 0, _ptr(out), ctypes.byref(sec))
+    if code != 0:
+        raise SppError("spp_schur_plan_host failed: %d" % code)
+    keys = ("nc", "nl", "no", "n_pairs", "n_sblk", "n_items", "n_multi", "checksum")
+    d = dict(zip(keys, (int(v) for v in out)))
+    d["seconds"] = sec.value
+    return d
 
 
 class DeviceArray:

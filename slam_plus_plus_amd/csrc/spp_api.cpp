@@ -401,6 +401,46 @@ int spp_block_ordering(int64_t nb, const int64_t *col_ptr, const int64_t *row_id
 	}
 }
 
+int spp_schur_plan_host(int64_t nb, const int32_t *dim, const int64_t *col_ptr, const int64_t *row_idx, int shard_rank,
+	int shard_world, int sparse_S, int64_t *out, double *seconds)
+{
+	if(nb <= 0 || !dim || !col_ptr || !row_idx || !out || shard_world < 1 || shard_rank < 0 || shard_rank >= shard_world)
+		return SPP_E_BADARG;
+	try {
+		Structure st;
+		st.nb = nb;
+		st.nnzb = col_ptr[nb];
+		st.col_ptr.assign(col_ptr, col_ptr + nb + 1);
+		st.row_idx.assign(row_idx, row_idx + st.nnzb);
+		st.dim.assign(dim, dim + nb);
+		st.base.resize(nb + 1);
+		st.base[0] = 0;
+		for(int64_t j = 0; j < nb; ++ j)
+			st.base[j + 1] = st.base[j] + dim[j];
+		st.n = st.base[nb];
+		st.blk_off.resize(st.nnzb);
+		int64_t off = 0;
+		for(int64_t j = 0; j < nb; ++ j)
+			for(int64_t p = col_ptr[j]; p < col_ptr[j + 1]; ++ p) {
+				if(row_idx[p] < 0 || row_idx[p] > j)
+					return SPP_E_BADARG; // upper triangle only
+				st.blk_off[p] = off;
+				off += (int64_t)dim[row_idx[p]] * dim[j];
+			}
+		st.nvals = off;
+		const double sec = schur_plan_host_probe(st, shard_rank, shard_world, sparse_S != 0, out);
+		if(seconds)
+			*seconds = sec;
+		return SPP_OK;
+	} catch(const Error &e) {
+		return e.code;
+	} catch(const std::bad_alloc &) {
+		return SPP_E_NOMEM;
+	} catch(...) {
+		return SPP_E_HIP;
+	}
+}
+
 int spp_schur_buffer_size(const spp_ctx *ctx, int64_t *n_doubles)
 {
 	if(!ctx || !n_doubles)

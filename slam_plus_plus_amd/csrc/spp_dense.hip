@@ -30,6 +30,7 @@
 #include "spp_internal.h"
 #include "spp_tiles.h"
 #include "spp_dense_dev.h"
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
@@ -49,7 +50,9 @@ constexpr int LDS_STRIDE = 18;   // doubles per tile column in LDS: conflict-fre
 // __launch_bounds__): 2 for the 512-thread configuration = one workgroup per CU and a 256-VGPR budget
 // (at the default budget of 128 the staging registers were spilled to scratch inside the k-loop)
 // one BM x BN tile of C at (m0, n0) by the whole workgroup (the body shared by the kernels below)
-template <int BM, int BN, int WM, int WN, int MODE, int DEPTH, int BKT>
+// SC1: the C tile is stored write-through (agent-scope atomic = sc1 stores): a tile another workgroup reads behind a
+// counter hand-off, without a release fence (lookahead schedule, the first tile rows of a bulk update)
+template <int BM, int BN, int WM, int WN, int MODE, int DEPTH, int BKT, int SC1 = 0>
 __device__ __forceinline__ void gemm_tn_tile(const int64_t m0, const int64_t n0, int64_t M, int64_t N, int K,
 	const double *__restrict__ A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, double *gemm_lds)
 {
@@ -192,7 +195,13 @@ __device__ __forceinline__ void gemm_tn_tile(const int64_t m0, const int64_t n0,
 #pragma unroll
 			for(int r = 0; r < 4; ++ r) {
 				if(mu + l15 < M && nu + l4 + 4 * r < N)
-					(Cu + (int64_t)(4 * r) * ldc)[c_lane] = (MODE == 0) ? -acc[b][a][r] : acc[b][a][r];
+				{
+					const double val = (MODE == 0) ? -acc[b][a][r] : acc[b][a][r];
+					if(SC1)
+						__hip_atomic_store(&(Cu + (int64_t)(4 * r) * ldc)[c_lane], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					else
+						(Cu + (int64_t)(4 * r) * ldc)[c_lane] = val;
+				}
 			}
 		}
 }
@@ -233,19 +242,30 @@ __device__ __forceinline__ void upper_tile_of(int64_t t, int nt, int &ti, int &t
 	ti = (int)(t - (int64_t)j * (j + 1) / 2);
 }
 
+} // namespace spp
+#include "spp_dense_444.h" // the 128 x 128 tile built around v_mfma_f64_4x4x4_4b (LDS-DMA staging, swizzled images)
+namespace spp {
+
 #ifndef SPP_MIXED_WAVES
 #define SPP_MIXED_WAVES 8 // waves per SIMD the register allocator leaves room for: 8 = two workgroups per CU at 64 VGPRs, 4 = one at 128
 #endif
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(SPP_MIXED_WAVES, SPP_MIXED_WAVES)))
 void gemm_tn_mixed_kernel(int64_t M, int64_t N, int K, const double *__restrict__ A, int64_t lda,
-	const double *B, int64_t ldb, double *C, int64_t ldc, int nt, int64_t n128)
+	const double *B, int64_t ldb, double *C, int64_t ldc, int nt, int64_t n128, int use444)
 {
-	extern __shared__ double gemm_lds[];
+	extern __shared__ __attribute__((aligned(16))) double gemm_lds[];
 	const int64_t b = blockIdx.x;
 	int ti, tj;
 	if(b < n128) {
 		upper_tile_of(b, nt, ti, tj);
-		gemm_tn_tile<128, 128, 32, 32, 0, 1, 16>((int64_t)ti * 128, (int64_t)tj * 128, M, N, K, A, lda, B, ldb, C, ldc, gemm_lds);
+		if(use444 && (int64_t)(ti + 1) * 128 <= M && (int64_t)(tj + 1) * 128 <= N) // (edge tiles: the bounds-checked tile)
+		{
+			if(use444 == 2)
+				gemm_tn_tile_444<0>((int64_t)ti * 128, (int64_t)tj * 128, K, A, lda, B, ldb, C, ldc, gemm_lds);
+			else
+				gemm_tn_tile_dma<0>((int64_t)ti * 128, (int64_t)tj * 128, K, A, lda, B, ldb, C, ldc, gemm_lds);
+		} else
+			gemm_tn_tile<128, 128, 32, 32, 0, 1, 16>((int64_t)ti * 128, (int64_t)tj * 128, M, N, K, A, lda, B, ldb, C, ldc, gemm_lds);
 	} else {
 		const int64_t q = b - n128;
 		upper_tile_of(n128 + (q >> 2), nt, ti, tj);
@@ -275,9 +295,17 @@ static bool launch_gemm_mixed(hipStream_t s, int64_t M, int64_t N, int K, const 
 	if(T < whole_below)
 		n128 = T;
 	const int64_t grid = n128 + 4 * (T - n128);
-	const size_t lds = (size_t)(128 + 128) * 18 * sizeof(double); // >= (64 + 64) * 34 doubles of the quarter path
+	static int use444 = -1;
+	if(use444 < 0) {
+		const char *e = getenv("SPP_TILE_444"); // whole 128 x 128 tiles: 0 register-staged 16x16x4 tile (rounds 1-2, default), 1 LDS-DMA 16x16x4 tile, 2 LDS-DMA 4x4x4_4b tile
+		use444 = e ? atoi(e) : 0;
+		SPP_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tn_mixed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+			T444_LDS_DOUBLES * (int)sizeof(double)));
+	}
+	const size_t lds = use444 ? (size_t)T444_LDS_DOUBLES * sizeof(double)
+		: (size_t)(128 + 128) * 18 * sizeof(double); // >= (64 + 64) * 34 doubles of the quarter path
 	hipLaunchKernelGGL(gemm_tn_mixed_kernel, dim3((unsigned)grid), dim3(1024), lds, s,
-		M, N, K, A, lda, B, ldb, C, ldc, (int)nt, n128);
+		M, N, K, A, lda, B, ldb, C, ldc, (int)nt, n128, use444);
 	return true;
 }
 
@@ -554,6 +582,10 @@ void update_potrf_kernel(int64_t M, int64_t N, const double *P, int64_t ld, doub
 	gemm_tn_staged_tile<64, 64, 16, 16, 0, 0>(bi * 64, bj * 64, M, N, P, ld, P, ld, C, ld, sm);
 }
 
+} // namespace spp
+#include "spp_dense_la.h" // the lookahead schedule: persistent chain kernel + one bulk launch per step
+namespace spp {
+
 // backward substitution step for block column k (rows/cols k0 .. k0 + NB):
 //   x_k = Tinv_k * y_k ; y_i -= R[i, k-block] x_k for all rows i < k0.
 // Every workgroup recomputes x_k (128 x 128 GEMV out of L2); workgroup 0 stores it to `xout`
@@ -746,7 +778,11 @@ static void ensure_info(spp_ctx *ctx)
 static void ensure_dense_work(spp_ctx *ctx, int64_t nblk)
 {
 	ensure_info(ctx);
-	ctx->dense.tinv_all.reserve((size_t)nblk * NB * NB);
+	if(ctx->dense.tinv_all.cap < (size_t)nblk * NB * NB) {
+		// zeroed once: the lookahead schedule never stores the zeros below the diagonal of a block's inverse
+		ctx->dense.tinv_all.reserve((size_t)nblk * NB * NB);
+		SPP_HIP_CHECK(hipMemsetAsync(ctx->dense.tinv_all.p, 0, ctx->dense.tinv_all.cap * sizeof(double), ctx->stream));
+	}
 	ctx->dense.xtmp.reserve((size_t)(nblk + 1) * NB);
 	if(!ctx->dense.aux) {
 		// the bulk update runs at the LOWEST priority: workgroups of the serial chain (on ctx->stream)
@@ -808,6 +844,183 @@ static void ensure_dense_work(spp_ctx *ctx, int64_t nblk)
 static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, int64_t n, int64_t rows, int64_t ncols,
 	int64_t nsteps, bool has_rhs, bool use_flags = false);
 static bool flag_schedule_usable(spp_ctx *ctx);
+static void flag_signal(hipStream_t st, int *flag, int value);
+static void flag_wait(spp_ctx *ctx, hipStream_t st, const int *flag, int value, double timeout_ms = 500.0);
+
+// ---- lookahead schedule (spp_dense_la.h): host side -------------------------------------------------------------------
+// Streams: the chain kernel runs on a stream of its own that is CU-masked to the `reserve` CUs the bulk stream's mask
+// leaves alone (it IS the reservation: 1 + LA_G1 + g2 <= reserve workgroups, one per CU, resident for the whole
+// factorization); the bulk launches go to the masked bulk stream. Both are forked from / joined into the ctx stream by
+// events, once per factorization.
+static void la_setup_streams(spp_ctx *ctx)
+{
+	DenseWork &dw = ctx->dense;
+	if(dw.la_state != 0)
+		return;
+	dw.la_state = -1;
+	const char *e = getenv("SPP_DENSE_LA"); // 1: the lookahead schedule (spp_dense_la.h); default: the two-stream schedule of rounds 1-2
+	if(!e || !atoi(e))
+		return;
+	hipDeviceProp_t prop;
+	SPP_HIP_CHECK(hipGetDeviceProperties(&prop, ctx->device));
+	const int ncu = prop.multiProcessorCount;
+	const char *r = getenv("SPP_AUX_RESERVE_CUS");
+	const int reserve = r ? atoi(r) : 32;
+	if(ncu < 128 || reserve < 1 + LA_G1 + 1 || reserve > ncu / 2 || !dw.aux)
+		return; // a small partition: the chain kernel's workgroups + a useful bulk side do not fit
+	dw.la_ncu = ncu;
+	dw.la_reserve = reserve;
+	const char *m = getenv("SPP_LA_CHAIN_MASK"); // 0: the chain kernel on an unmasked stream
+	const int nw = (ncu + 31) / 32;
+	std::vector<uint32_t> mask((size_t)nw, 0u);
+	for(int c = 0; c < reserve; ++ c)
+		mask[(size_t)c / 32] |= 1u << (c % 32);
+	if((m && !atoi(m)) || hipExtStreamCreateWithCUMask(&dw.chain, (uint32_t)nw, mask.data()) != hipSuccess) {
+		(void)hipGetLastError();
+		SPP_HIP_CHECK(hipStreamCreateWithFlags(&dw.chain, hipStreamNonBlocking));
+	}
+	SPP_HIP_CHECK(hipEventCreateWithFlags(&dw.ev_chain, hipEventDisableTiming));
+	// the chain stream and the bulk stream must run CONCURRENTLY (two streams that share a hardware queue would make the
+	// bulk launches wait for the end of the chain kernel, which waits for them): wait enqueued first, both directions
+	dw.sync.reserve(16);
+	SPP_HIP_CHECK(hipMemsetAsync(dw.sync.p, 0, 16 * sizeof(int), ctx->stream));
+	SPP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	hipStream_t st[2] = {dw.chain, dw.aux};
+	for(int p = 0; p < 2; ++ p) {
+		flag_wait(ctx, st[p], dw.sync.p + 8 + p, 1, 20.0);
+		flag_signal(st[1 - p], dw.sync.p + 8 + p, 1);
+	}
+	for(int i = 0; i < 2; ++ i)
+		SPP_HIP_CHECK(hipStreamSynchronize(st[i]));
+	int h_abort = 0;
+	SPP_HIP_CHECK(hipMemcpy(&h_abort, dw.info.p + 2, sizeof(int), hipMemcpyDeviceToHost));
+	if(h_abort) {
+		SPP_HIP_CHECK(hipMemset(dw.info.p + 2, 0, sizeof(int)));
+		return;
+	}
+	static bool attr = false;
+	if(!attr) {
+		SPP_HIP_CHECK(hipFuncSetAttribute((const void*)la_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+			LA_LDS_DOUBLES * (int)sizeof(double)));
+		attr = true;
+	}
+	dw.la_state = 1;
+}
+
+static bool la_usable(spp_ctx *ctx, int64_t nsteps)
+{
+	DenseWork &dw = ctx->dense;
+	if(nsteps < 6 || dw.sync_state < 0)
+		return false;
+	hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+	if(hipStreamIsCapturing(ctx->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone)
+		return false; // counters are zeroed and polled inside one call: not for a captured graph
+	la_setup_streams(ctx);
+	return dw.la_state == 1;
+}
+
+static void dense_factor_lookahead(spp_ctx *ctx, double *d_A, int64_t ld, int64_t n, int64_t rows, int64_t ncols,
+	int64_t nsteps, bool has_rhs)
+{
+	DenseWork &dw = ctx->dense;
+	hipStream_t s = ctx->stream, sb = dw.aux, sc = dw.chain;
+	LaArgs a;
+	a.A = d_A;
+	a.ld = ld;
+	a.n_id = (dw.ident_from >= 0 && dw.ident_from < n) ? dw.ident_from : n;
+	a.rows = rows;
+	a.ncols = ncols;
+	a.nsteps = (int)nsteps;
+	a.nt = (int)((ncols + NB - 1) / NB);
+	a.has_rhs = has_rhs ? 1 : 0;
+	a.g1 = LA_G1;
+	static int g2_env = -1, acq = -1, trace_n = -1;
+	static int64_t slots_env = -1;
+	if(g2_env < 0) {
+		const char *e = getenv("SPP_LA_G2");
+		g2_env = e ? atoi(e) : 0;
+		e = getenv("SPP_LA_BULK_ACQUIRE");
+		acq = e ? atoi(e) : 1;
+		e = getenv("SPP_LA_SLOTS");
+		slots_env = e ? atol(e) : 0;
+		e = getenv("SPP_LA_TRACE"); // n: the n-th factorization prints when its diagonal blocks started / ended
+		trace_n = e ? atoi(e) : 0;
+	}
+	a.g2 = g2_env > 0 ? std::min(g2_env, dw.la_reserve - 1 - LA_G1) : dw.la_reserve - 1 - LA_G1;
+	a.tinv_all = dw.tinv_all.p;
+	a.info = dw.info.p;
+	const size_t nints = (la_counter_ints(a.nsteps, a.nt) + 3) & ~(size_t)3;
+	dw.la_cnt.reserve(nints);
+	a.cnt = dw.la_cnt.p;
+	a.abort = dw.info.p + 2;
+	a.timeout_ticks = (long long)(500.0 * 1e5);
+	a.bulk_acquire = acq;
+	{
+		static int u = -1;
+		if(u < 0) {
+			const char *e = getenv("SPP_TILE_444");
+			u = e ? atoi(e) : 0;
+			SPP_HIP_CHECK(hipFuncSetAttribute((const void*)la_bulk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+				LA_BULK_LDS_DOUBLES * (int)sizeof(double)));
+		}
+		a.use444 = u;
+	}
+	a.trace = nullptr;
+	static int la_calls = 0;
+	const bool tracing = trace_n > 0 && ++ la_calls == trace_n;
+	if(tracing) {
+		const size_t nw = (size_t)12 * nsteps + 16;
+		dw.la_trace.reserve(nw);
+		std::vector<long long> init(nw, 0);
+		for(int64_t k = 0; k < nsteps; ++ k)
+			init[8 * nsteps + 8 + 4 * k] = (long long)((~0ull) >> 1); // atomicMin slot
+		SPP_HIP_CHECK(hipMemcpyAsync(dw.la_trace.p, init.data(), nw * sizeof(long long), hipMemcpyHostToDevice, s));
+		SPP_HIP_CHECK(hipStreamSynchronize(s));
+		a.trace = dw.la_trace.p;
+	}
+	SPP_HIP_CHECK(hipMemsetAsync(a.cnt, 0, nints * sizeof(int), s));
+	SPP_HIP_CHECK(hipEventRecord(dw.ev[0], s));
+	SPP_HIP_CHECK(hipStreamWaitEvent(sc, dw.ev[0], 0));
+	SPP_HIP_CHECK(hipStreamWaitEvent(sb, dw.ev[0], 0));
+	hipLaunchKernelGGL(la_chain_kernel, dim3((unsigned)(1 + LA_G1 + a.g2)), dim3(LA_THREADS), LA_LDS_DOUBLES * sizeof(double), sc, a);
+	const int64_t slots = slots_env > 0 ? slots_env : 512; // the first multiple of this many tiles of a launch go whole, the rest in quarters
+	for(int k = 0; k < a.nsteps; ++ k) {
+		const int64_t c1 = (int64_t)NB * (k + 1);
+		if(c1 >= ncols || rows - c1 <= 0)
+			break;
+		const int nr = (int)((rows - c1 + NB - 1) / NB), nc = (int)((ncols - c1 + NB - 1) / NB);
+		const int npri = (nc > 2) ? (nc - 2) + std::min(2, nr - 1) : 0; // row 0 from column 2 on, (1, 2), (2, 2)
+		const int64_t ntr = nr - 1, ntc = nc - 1;
+		const int64_t T = ntr > 0 ? ntr * (ntr + 1) / 2 + (ntc - ntr) * ntr : 0;
+		const int64_t n128 = (T / slots) * slots;
+		const int64_t grid = 4 * (int64_t)npri + n128 + 4 * (T - n128);
+		if(grid > 0)
+			hipLaunchKernelGGL(la_bulk_kernel, dim3((unsigned)grid), dim3(1024), LA_BULK_LDS_DOUBLES * sizeof(double), sb,
+				a, k, nr, nc, npri, n128);
+	}
+	SPP_HIP_CHECK(hipEventRecord(dw.ev[1], sb));
+	SPP_HIP_CHECK(hipEventRecord(dw.ev_chain, sc));
+	SPP_HIP_CHECK(hipStreamWaitEvent(s, dw.ev[1], 0));
+	SPP_HIP_CHECK(hipStreamWaitEvent(s, dw.ev_chain, 0));
+	SPP_HIP_CHECK(hipGetLastError());
+	if(tracing) {
+		std::vector<long long> h((size_t)12 * nsteps + 16);
+		SPP_HIP_CHECK(hipMemcpyAsync(h.data(), dw.la_trace.p, h.size() * sizeof(long long), hipMemcpyDeviceToHost, s));
+		SPP_HIP_CHECK(hipStreamSynchronize(s));
+		fprintf(stderr, "[spp] lookahead factorization, %d steps: potrf start / duration / gap to the next start (us)\n", a.nsteps);
+		for(int k = 0; k < a.nsteps; ++ k)
+			fprintf(stderr, "  k %2d  start %8.1f  potrf %5.1f  publish %4.1f | b1 seen +%4.1f  done +%4.1f | c1 seen +%4.1f  done +%4.1f | step %5.1f\n", k,
+				(h[8 * k] - h[0]) * 0.01, (h[8 * k + 2] - h[8 * k]) * 0.01, (h[8 * k + 1] - h[8 * k + 2]) * 0.01,
+				(h[8 * k + 3] - h[8 * k + 1]) * 0.01, (h[8 * k + 4] - h[8 * k + 1]) * 0.01, (h[8 * k + 5] - h[8 * k + 1]) * 0.01,
+				(h[8 * k + 6] - h[8 * k + 1]) * 0.01, k + 1 < a.nsteps ? (h[8 * (k + 1)] - h[8 * k]) * 0.01 : 0.0);
+		fprintf(stderr, "[spp] per step: panel (rest) done / bulk launch: first tile starts, priority tiles done, last tile done, busy workgroup-us (all relative to potrf(0) start)\n");
+		for(int k = 0; k < a.nsteps; ++ k) {
+			const long long *b = h.data() + 8 * nsteps + 8 + 4 * k;
+			fprintf(stderr, "  k %2d  panel done %8.1f | bulk start %8.1f  pri done %8.1f  end %8.1f  busy %9.1f\n", k, h[8 * k + 7] ? (h[8 * k + 7] - h[0]) * 0.01 : 0.0,
+				b[1] ? (b[0] - h[0]) * 0.01 : 0.0, b[3] ? (b[3] - h[0]) * 0.01 : 0.0, b[1] ? (b[1] - h[0]) * 0.01 : 0.0, b[2] * 0.01);
+		}
+	}
+}
 
 // Optional (SPP_DENSE_GRAPH=1): the two-stream schedule of one factorization is captured into a hipGraph
 // the second time the same (buffer, shape) is factored and replayed afterwards -- the kernel arguments
@@ -823,6 +1036,10 @@ void dense_factor_steps(spp_ctx *ctx, double *d_A, int64_t ld, int64_t n, int64_
 		use_graph = e ? atoi(e) : 0;
 	}
 	DenseWork &dw = ctx->dense;
+	if(la_usable(ctx, nsteps)) { // lookahead: persistent chain kernel + one bulk launch per step
+		dense_factor_lookahead(ctx, d_A, ld, n, rows, ncols, nsteps, has_rhs);
+		return;
+	}
 	if(nsteps >= 4 && flag_schedule_usable(ctx)) { // cross-stream hand-offs through device flags instead of events
 		dense_factor_steps_enqueue(ctx, d_A, ld, n, rows, ncols, nsteps, has_rhs, true);
 		return;
@@ -871,7 +1088,7 @@ static FlagWait make_flag_wait(spp_ctx *ctx, const int *flag, int value, double 
 	return FlagWait{flag, value, ctx->dense.info.p + 2, (long long)(timeout_ms * 1e5)};
 }
 
-static void flag_wait(spp_ctx *ctx, hipStream_t st, const int *flag, int value, double timeout_ms = 500.0)
+static void flag_wait(spp_ctx *ctx, hipStream_t st, const int *flag, int value, double timeout_ms)
 {
 	hipLaunchKernelGGL(flag_wait_kernel, dim3(1), dim3(64), 0, st, make_flag_wait(ctx, flag, value, timeout_ms));
 }

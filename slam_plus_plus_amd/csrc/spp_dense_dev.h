@@ -207,7 +207,20 @@ __device__ __forceinline__ double2 ld_blk2(const double *p)
 	return *(const double2*)p;
 }
 
-template <bool COH = false>
+// WT: R and the inverse are stored write-through (agent-scope atomic = sc1 stores): the block is handed to other workgroups
+// of the same launch behind a drained flag, without a release fence that would write back the whole L2 (lookahead chain)
+template <int WT>
+__device__ __forceinline__ void st_blk(double *p, const double v)
+{
+	if(WT)
+		__hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	else
+		*p = v;
+}
+
+// WT = 2: as 1, and the zeros below the diagonal of the inverse are NOT stored (the buffer is zeroed when it is allocated
+// and nothing else is ever written there): a third fewer stores behind the factorization
+template <bool COH = false, int WT = 0>
 __device__ __forceinline__ void potrf_diag_body(double *__restrict__ Ablk, int64_t ld, int n_valid, int has_rhs,
 	double *__restrict__ tinv, int *__restrict__ info, int64_t k0, double *sm)
 {
@@ -317,11 +330,12 @@ __device__ __forceinline__ void potrf_diag_body(double *__restrict__ Ablk, int64
 			for(int e = tid; e < 16 * (NB - j0); e += POTRF_THREADS) {
 				const int r = j0 + (e & 15), c = j0 + (e >> 4);
 				if(r <= c && c != rhs_col)
-					Ablk[r + (int64_t)c * ld] = (r == c) ? 1.0 : 0.0;
+					st_blk<WT>(&Ablk[r + (int64_t)c * ld], (r == c) ? 1.0 : 0.0);
 			}
 			for(int e = tid; e < 16 * NB; e += POTRF_THREADS) {
 				const int r = e & (NB - 1), c = j0 + (e >> 7);
-				tinv[r + c * NB] = (r == c) ? 1.0 : ((r < c && r < nv16) ? T[c + r * TS] : 0.0); // G[c][r] of the valid rows: zeros, assigned there
+				if(WT < 2 || r <= c)
+					st_blk<WT>(&tinv[r + c * NB], (r == c) ? 1.0 : ((r < c && r < nv16) ? T[c + r * TS] : 0.0)); // G[c][r] of the valid rows: zeros, assigned there
 			}
 			continue;
 		}
@@ -445,7 +459,7 @@ __device__ __forceinline__ void potrf_diag_body(double *__restrict__ Ablk, int64
 					for(int e = t15; e < 16 * (NB - j0); e += (NW - 1) * 64) { // R: 16 rows x (NB - j0) columns
 						const int r = j0 + (e & 15), c = j0 + (e >> 4);
 						if(r <= c && c != rhs_col)
-							Ablk[r + (int64_t)c * ld] = T[r + c * TS];
+							st_blk<WT>(&Ablk[r + (int64_t)c * ld], T[r + c * TS]);
 					}
 					for(int e = t15; e < 16 * NB; e += (NW - 1) * 64) { // inverse: columns j0 .. j0+15, all 128 rows
 						const int r = e & (NB - 1), c = j0 + (e >> 7);
@@ -454,7 +468,8 @@ __device__ __forceinline__ void potrf_diag_body(double *__restrict__ Ablk, int64
 							v = dinv[r];
 						else if(r < c)
 							v = T[c + r * TS]; // G[c][r]
-						tinv[r + c * NB] = v;
+						if(WT < 2 || r <= c)
+							st_blk<WT>(&tinv[r + c * NB], v);
 					}
 				}
 				// rhs: y_i -= sum_k P[k][i] y_J[k], by the threads of waves 8..9
@@ -476,7 +491,7 @@ __device__ __forceinline__ void potrf_diag_body(double *__restrict__ Ablk, int64
 		return;
 	// R and the inverse went back block row by block row inside the loop; the carried rhs remains
 	if(rhs_col >= 0 && tid < n_valid)
-		Ablk[tid + (int64_t)rhs_col * ld] = yv[tid];
+		st_blk<WT>(&Ablk[tid + (int64_t)rhs_col * ld], yv[tid]);
 	SPP_STAMP(52, 0);
 }
 

@@ -160,6 +160,15 @@ struct DenseWork {
 	std::vector<int> fuse_expect;  // host: the value every counter will have reached behind the launches enqueued so far
 	bool fuse_dirty = false;       // counters and bookkeeping disagree (aborted factorization): cleared before the next use
 	int64_t ident_from = -1;       // >= 0: the pivots from this index on are exact identity padding (set around a call by the sparse path)
+	// lookahead factorization (spp_dense_la.h): persistent chain kernel on its own stream (CU-masked to the reserved CUs),
+	// counters of one factorization, and whether the chain / bulk stream pair was seen to run concurrently
+	hipStream_t chain = nullptr;
+	hipEvent_t ev_chain = nullptr;
+	DevBuf<int> la_cnt;
+	DevBuf<long long> la_trace;
+	int la_state = 0;              // 0: untested, 1: usable, -1: off
+	int la_reserve = 0;            // CUs kept free of the bulk stream (= workgroups the chain kernel may have)
+	int la_ncu = 0;
 	int sync_epoch = 0;
 	int sync_state = 0;            // 0: not tested on this stream, 1: the streams run concurrently, -1: disabled
 	hipStream_t sync_stream = nullptr; // the ctx stream the self-test ran against
@@ -237,6 +246,7 @@ void nested_dissection_order(int64_t nb, const int64_t *col_ptr, const int64_t *
 void build_schur_plan(spp_ctx *ctx, bool sparse_S, bool mis = false);
 int64_t schur_buffer_doubles(const spp_ctx *ctx); // S | rhs buffer the Schur entry points work on
 bool schur_applicable(const Structure &st, int *dp, int *dl);
+double schur_plan_host_probe(const Structure &st, int shard_rank, int shard_world, bool sparse_S, int64_t *out); // host only: plan + checksum, seconds
 
 // ---- spp_sparse (symbolic on host + numeric on device) ----
 void sparse_analyze(spp_ctx *ctx, const Structure &st); // plan for `st` (Lambda, or the sparse reduced system)

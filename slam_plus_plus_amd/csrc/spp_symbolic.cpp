@@ -17,6 +17,10 @@
 #include <numeric>
 #include <string.h>
 #include <stdlib.h>
+#include <stdio.h>
+#include <thread>
+#include <chrono>
+#include <exception>
 
 namespace spp {
 
@@ -115,14 +119,110 @@ static bool mis_partition(const Structure &st, std::vector<uint8_t> &is_lm, int 
 	return n_lm > 0 && n_lm < st.nb;
 }
 
-void build_schur_plan(spp_ctx *ctx, bool sparse_S, bool mis)
+// Runs fn(t) for t = 0 .. nt-1 on nt host threads (fn(0) on the caller's). The symbolic phase is integer work over
+// tens of millions of block products; its passes are cut into independent pieces with precomputed output offsets, so
+// the result does not depend on the number of threads.
+template <class F>
+static void run_threads(int nt, F fn)
 {
-	const Structure &st = ctx->st;
-	SchurPlan &sp = ctx->schur;
-	sp.release_all();
-	sp.sparse_S = sparse_S;
-	int dp, dl;
+	if(nt <= 1) {
+		fn(0);
+		return;
+	}
+	std::vector<std::thread> th;
+	std::exception_ptr err[64];
+	for(int t = 1; t < nt; ++ t)
+		th.emplace_back([&, t]() { try { fn(t); } catch(...) { err[t] = std::current_exception(); } });
+	try { fn(0); } catch(...) { err[0] = std::current_exception(); }
+	for(size_t t = 0; t < th.size(); ++ t)
+		th[t].join();
+	for(int t = 0; t < nt; ++ t)
+		if(err[t])
+			std::rethrow_exception(err[t]);
+}
+
+static int plan_threads(int64_t work)
+{
+	static int env = -1;
+	if(env < 0) {
+		const char *e = getenv("SPP_PLAN_THREADS"); // host threads of the symbolic phase (default: up to 16)
+		env = e ? std::max(1, atoi(e)) : 0;
+	}
+	int nt = env ? env : (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+	if(work < (int64_t(1) << 18))
+		nt = 1; // small problems: a thread costs more than it saves
+	return std::min(nt, 64);
+}
+
+// cut [0, n) into nt pieces of about equal weight; w_prefix has n + 1 entries (w_prefix[0] = 0)
+static void balanced_cuts(const std::vector<int64_t> &w_prefix, int nt, std::vector<int64_t> &cut)
+{
+	const int64_t n = (int64_t)w_prefix.size() - 1, total = w_prefix[n];
+	cut.assign(nt + 1, n);
+	cut[0] = 0;
+	for(int t = 1; t < nt; ++ t)
+		cut[t] = std::lower_bound(w_prefix.begin(), w_prefix.end(), total * t / nt) - w_prefix.begin();
+	for(int t = 1; t <= nt; ++ t)
+		cut[t] = std::max(cut[t], cut[t - 1]);
+	cut[nt] = n;
+}
+
+// uninitialized host array (a std::vector would zero-fill -- and page-fault -- 100 MB on one thread)
+template <class T>
+struct RawBuf {
+	T *p = nullptr;
+	size_t n = 0;
+	RawBuf() {}
+	RawBuf(const RawBuf&) = delete;
+	RawBuf &operator=(const RawBuf&) = delete;
+	~RawBuf() { free(p); }
+	void resize(size_t m)
+	{
+		free(p);
+		p = m ? (T*)malloc(m * sizeof(T)) : nullptr;
+		if(m && !p)
+			throw std::bad_alloc();
+		n = m;
+	}
+	size_t size() const { return n; }
+	T &operator[](size_t i) { return p[i]; }
+	const T &operator[](size_t i) const { return p[i]; }
+};
+
+// Everything build_schur_plan() derives from the block structure, in host memory: the pure symbolic part (no device,
+// no ctx), also reachable through spp_schur_plan_host() for host-only tests and timing.
+struct SchurPlanHost {
+	int dp = 0, dl = 0;
+	int64_t nc = 0, nl = 0, nl_total = 0, no = 0, n_red = 0, ld = 0, n_sblk = 0, n_pairs = 0, n_items = 0, n_multi = 0, n_ablk = 0;
+	int32_t n_slots = 0, xcd_max_items = 0;
+	bool u_landmark_major = true;
+	std::vector<int64_t> pose_block, lm_block;
 	std::vector<uint8_t> is_lm;
+	std::vector<int32_t> lm_ptr, obs_pose, obs_lm, cam_ptr, cam_obs, wpos, sblk_i1, sblk_i2, multi_blk, multi_ptr, xb;
+	RawBuf<int32_t> pair_a, pair_b; // (tens of millions of entries: not value-initialized, first touched by the threads that fill them)
+	std::vector<int64_t> lm_coff, obs_off, sblk_aoff, sblk_voff, pose_rbase, lm_rbase;
+	std::vector<SaccItem> recs;
+	Structure s_st;
+};
+
+struct PlanClock {
+	std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+	bool on = getenv("SPP_VERBOSE") != nullptr;
+	void lap(const char *what)
+	{
+		if(!on)
+			return;
+		const auto n = std::chrono::steady_clock::now();
+		fprintf(stderr, "[spp] schur plan: %-28s %7.2f ms\n", what, std::chrono::duration<double>(n - t).count() * 1e3);
+		t = n;
+	}
+};
+
+static void schur_plan_host(const Structure &st, int shard_rank, int shard_world, bool sparse_S, bool mis, SchurPlanHost &h)
+{
+	PlanClock clk;
+	int dp, dl;
+	std::vector<uint8_t> &is_lm = h.is_lm;
 	if(mis) {
 		SPP_REQUIRE(mis_partition(st, is_lm, &dp), SPP_E_UNSUPPORTED,
 			"MIS Schur mode needs a graph of one block width (3 or 6) with at least one edge");
@@ -134,9 +234,8 @@ void build_schur_plan(spp_ctx *ctx, bool sparse_S, bool mis)
 		for(int64_t j = 0; j < st.nb; ++ j)
 			is_lm[j] = st.dim[j] == dl;
 	}
-	sp.dp = dp;
-	sp.dl = dl;
-	hipStream_t s = ctx->stream;
+	h.dp = dp;
+	h.dl = dl;
 
 	// ---- guided ordering: stable partition by width (LinearSolver_Schur.cpp:771-838)
 	std::vector<int32_t> pose_of(st.nb, -1), lm_of(st.nb, -1);
@@ -144,32 +243,34 @@ void build_schur_plan(spp_ctx *ctx, bool sparse_S, bool mis)
 	for(int64_t j = 0; j < st.nb; ++ j) {
 		if(!is_lm[j]) {
 			pose_of[j] = (int32_t)nc ++;
-			sp.pose_block.push_back(j);
+			h.pose_block.push_back(j);
 		} else {
 			// landmark sharding: round-robin over ranks keeps track lengths balanced
-			if(nl_total % ctx->shard_world == ctx->shard_rank) {
+			if(nl_total % shard_world == shard_rank) {
 				lm_of[j] = (int32_t)nl ++;
-				sp.lm_block.push_back(j);
+				h.lm_block.push_back(j);
 			}
 			++ nl_total;
 		}
 	}
-	sp.is_lm = is_lm;
-	sp.nc = nc;
-	sp.nl = nl;
-	sp.nl_total = nl_total;
-	sp.add_A = (ctx->shard_rank == 0);
-	sp.n_red = nc * dp;
-	sp.ld = ((sp.n_red + 1 + DENSE_NB - 1) / DENSE_NB) * DENSE_NB; // at least one padding column (rhs)
-	SPP_REQUIRE(sparse_S || sp.ld <= 65536, SPP_E_UNSUPPORTED,
+	h.nc = nc;
+	h.nl = nl;
+	h.nl_total = nl_total;
+	const bool add_A = (shard_rank == 0);
+	h.n_red = nc * dp;
+	h.ld = ((h.n_red + 1 + DENSE_NB - 1) / DENSE_NB) * DENSE_NB; // at least one padding column (rhs)
+	SPP_REQUIRE(sparse_S || h.ld <= 65536, SPP_E_UNSUPPORTED,
 		"reduced camera system too large for the dense path (use SPP_MODE_SCHUR_SPARSE)");
 
 	// ---- observations: every pose-landmark block, sorted by (landmark, pose)
 	struct Obs { int32_t lm, pose; int64_t off; };
 	std::vector<Obs> obs;
-	std::vector<int64_t> lm_coff(nl, -1);
+	obs.reserve((size_t)st.nnzb);
+	std::vector<int64_t> &lm_coff = h.lm_coff;
+	lm_coff.assign(nl, -1);
 	struct ABlk { int32_t i1, i2; int64_t off; };
 	std::vector<ABlk> ablk;
+	bool obs_sorted = true;
 	for(int64_t j = 0; j < st.nb; ++ j) {
 		for(int64_t p = st.col_ptr[j]; p < st.col_ptr[j + 1]; ++ p) {
 			const int64_t i = st.row_idx[p]; // i <= j
@@ -179,22 +280,32 @@ void build_schur_plan(spp_ctx *ctx, bool sparse_S, bool mis)
 			else if(!pi && !pj) {
 				if(lm_of[j] >= 0)
 					lm_coff[lm_of[j]] = st.blk_off[p]; // diagonal C block
-			} else if(pi) { // block (pose i, landmark j): dp x dl as stored
-				if(lm_of[j] >= 0)
-					obs.push_back({lm_of[j], pose_of[i], st.blk_off[p] << 1});
-			} else {       // block (landmark i, pose j): stored transposed, dl x dp
-				if(lm_of[i] >= 0)
-					obs.push_back({lm_of[i], pose_of[j], (st.blk_off[p] << 1) | 1});
+			} else {
+				Obs o;
+				if(pi) { // block (pose i, landmark j): dp x dl as stored
+					if(lm_of[j] < 0)
+						continue;
+					o = {lm_of[j], pose_of[i], st.blk_off[p] << 1};
+				} else { // block (landmark i, pose j): stored transposed, dl x dp
+					if(lm_of[i] < 0)
+						continue;
+					o = {lm_of[i], pose_of[j], (st.blk_off[p] << 1) | 1};
+				}
+				if(!obs.empty() && (o.lm < obs.back().lm || (o.lm == obs.back().lm && o.pose < obs.back().pose)))
+					obs_sorted = false;
+				obs.push_back(o);
 			}
 		}
 	}
+	h.n_ablk = (int64_t)ablk.size();
+	clk.lap("partition + observation scan");
 	for(int64_t l = 0; l < nl; ++ l)
 		SPP_REQUIRE(lm_coff[l] >= 0, SPP_E_BADARG, "landmark without a diagonal block");
 	// Sharded + sparse reduced system: every rank must hold the SAME block structure of S (the union
 	// over all landmarks), or the all-reduce of the value arrays would add unrelated blocks. The pattern
 	// of the landmarks this rank does not own is collected here (pose lists per foreign landmark).
 	std::vector<std::vector<int32_t> > foreign_cols; // per pose i1: poses i2 > i1 co-observing a foreign landmark
-	if(sparse_S && ctx->shard_world > 1) {
+	if(sparse_S && shard_world > 1) {
 		std::vector<int64_t> lm_gidx(st.nb, -1);
 		int64_t g = 0;
 		for(int64_t j = 0; j < st.nb; ++ j)
@@ -223,13 +334,19 @@ void build_schur_plan(spp_ctx *ctx, bool sparse_S, bool mis)
 			foreign_cols[c].erase(std::unique(foreign_cols[c].begin(), foreign_cols[c].end()), foreign_cols[c].end());
 		}
 	}
-	std::sort(obs.begin(), obs.end(), [](const Obs &a, const Obs &b) {
-		return a.lm != b.lm ? a.lm < b.lm : a.pose < b.pose; });
+	// (cameras before points, the usual numbering: the column scan above already emits the observations in order)
+	if(!obs_sorted)
+		std::sort(obs.begin(), obs.end(), [](const Obs &a, const Obs &b) {
+			return a.lm != b.lm ? a.lm < b.lm : a.pose < b.pose; });
 	const int64_t no = (int64_t)obs.size();
 	SPP_REQUIRE(no < (int64_t(1) << 31), SPP_E_UNSUPPORTED, "too many observations for 32-bit obs indices");
-	sp.no = no;
-	std::vector<int32_t> lm_ptr(nl + 1, 0), obs_pose(no), obs_lm(no);
-	std::vector<int64_t> obs_off(no);
+	h.no = no;
+	std::vector<int32_t> &lm_ptr = h.lm_ptr, &obs_pose = h.obs_pose, &obs_lm = h.obs_lm;
+	std::vector<int64_t> &obs_off = h.obs_off;
+	lm_ptr.assign(nl + 1, 0);
+	obs_pose.resize(no);
+	obs_lm.resize(no);
+	obs_off.resize(no);
 	for(int64_t a = 0; a < no; ++ a) {
 		++ lm_ptr[obs[a].lm + 1];
 		obs_pose[a] = obs[a].pose;
@@ -238,9 +355,12 @@ void build_schur_plan(spp_ctx *ctx, bool sparse_S, bool mis)
 	}
 	for(int64_t l = 0; l < nl; ++ l)
 		lm_ptr[l + 1] += lm_ptr[l];
+	std::vector<Obs>().swap(obs);
 
 	// ---- per-pose observation lists (ascending landmark = ascending obs index)
-	std::vector<int32_t> cam_ptr(nc + 1, 0), cam_obs(no);
+	std::vector<int32_t> &cam_ptr = h.cam_ptr, &cam_obs = h.cam_obs;
+	cam_ptr.assign(nc + 1, 0);
+	cam_obs.resize(no);
 	for(int64_t a = 0; a < no; ++ a)
 		++ cam_ptr[obs_pose[a] + 1];
 	for(int64_t c = 0; c < nc; ++ c)
@@ -253,100 +373,176 @@ void build_schur_plan(spp_ctx *ctx, bool sparse_S, bool mis)
 
 	// camera-major position of every observation: W, Up, xw are stored in this order, so that the
 	// blocks one camera contributes are contiguous (the S accumulation gathers them per camera pair)
-	std::vector<int32_t> wpos(no);
+	std::vector<int32_t> &wpos = h.wpos;
+	wpos.resize(no);
 	for(int64_t q = 0; q < no; ++ q)
 		wpos[cam_obs[q]] = (int32_t)q;
 
-	// ---- S block pattern and pair lists. Key = (i1 <= i2). Two stable counting passes
-	// (by i1, then by i2... ) would reorder landmarks; instead count per key with a dense or
-	// hashed index and fill in landmark order, which keeps the reference's accumulation order
-	// (MultiplyToWith_FBS walks the columns of V = landmarks in ascending order).
-	int64_t n_pairs = 0;
+	clk.lap("observation / camera lists");
+	// ---- S block pattern and pair lists. Key = (i1 <= i2). The pairs of a block keep the landmark order, which is the
+	// reference's accumulation order (MultiplyToWith_FBS walks the columns of V = landmarks in ascending order).
+	// Pass 1 buckets the pairs by row i1, pass 2 is a counting sort by i2 inside each row. Both run on host threads:
+	// pass 1 over chunks of landmarks (per-chunk, per-row counts give every chunk its place in every bucket), pass 2
+	// over ranges of rows (the rows' output ranges are known from pass 1).
+	std::vector<int64_t> lm_pairs(nl + 1, 0);
 	for(int64_t l = 0; l < nl; ++ l) {
-		int64_t k = lm_ptr[l + 1] - lm_ptr[l];
-		n_pairs += k * (k + 1) / 2;
+		const int64_t k = lm_ptr[l + 1] - lm_ptr[l];
+		lm_pairs[l + 1] = lm_pairs[l] + k * (k + 1) / 2;
 	}
+	const int64_t n_pairs = lm_pairs[nl];
 	SPP_REQUIRE(n_pairs < (int64_t(1) << 31), SPP_E_UNSUPPORTED, "too many block products for 32-bit pair indices");
-	sp.n_pairs = n_pairs;
-	// sort-free grouping: first pass counts pairs per row i1 (bucket), second pass sorts each
-	// bucket's keys by i2 with a counting sort over nc. Memory: O(n_pairs).
-	std::vector<int32_t> pair_a(n_pairs), pair_b(n_pairs);
-	std::vector<int32_t> sblk_i1, sblk_i2;
-	std::vector<int64_t> sblk_aoff;
-	std::vector<int64_t> sblk_beg; // pair range per S block
+	h.n_pairs = n_pairs;
 	{
-		// bucket by i1
+		const char *e = getenv("SPP_SACC_ULM");
+		h.u_landmark_major = e ? atoi(e) != 0 : true;
+	}
+	RawBuf<int32_t> &pair_a = h.pair_a, &pair_b = h.pair_b;
+	pair_a.resize(n_pairs);
+	pair_b.resize(n_pairs);
+	{
+		// first touch in parallel, in order: the fill below writes ~200 000 interleaved streams, and page faults taken in
+		// that order by many threads at once serialize in the kernel
+		const int ntt = plan_threads(n_pairs);
+		run_threads(ntt, [&](int t) {
+			const int64_t b = n_pairs * t / ntt, e = n_pairs * (t + 1) / ntt;
+			memset(pair_a.p + b, 0, (size_t)(e - b) * sizeof(int32_t));
+			memset(pair_b.p + b, 0, (size_t)(e - b) * sizeof(int32_t));
+		});
+	}
+	clk.lap("pair list buffers");
+	std::vector<int32_t> &sblk_i1 = h.sblk_i1, &sblk_i2 = h.sblk_i2;
+	std::vector<int64_t> &sblk_aoff = h.sblk_aoff;
+	std::vector<int64_t> sblk_beg; // pair range per S block
+	const int nt = plan_threads(n_pairs);
+	const bool ulm = h.u_landmark_major;
+	std::vector<int64_t> lcut;
+	balanced_cuts(lm_pairs, nt, lcut);
+	// A blocks grouped by row for merging
+	std::vector<std::vector<std::pair<int32_t, int64_t> > > a_by_row(nc);
+	for(size_t q = 0; q < ablk.size(); ++ q)
+		a_by_row[ablk[q].i1].push_back(std::make_pair(ablk[q].i2, ablk[q].off));
+	{
+		// pass 1 buckets the pairs by row i1 (with the column i2 beside them), pass 2 is a counting sort by i2 inside each row
+		std::vector<int64_t> cnt((size_t)nt * nc, 0); // [chunk][row]
+		run_threads(nt, [&](int t) {
+			int64_t *c = cnt.data() + (size_t)t * nc;
+			for(int64_t l = lcut[t]; l < lcut[t + 1]; ++ l)
+				for(int32_t a = lm_ptr[l]; a < lm_ptr[l + 1]; ++ a)
+					c[obs_pose[a]] += lm_ptr[l + 1] - a; // pairs (a, b >= a)
+		});
 		std::vector<int64_t> row_cnt(nc + 1, 0);
-		for(int64_t l = 0; l < nl; ++ l)
-			for(int32_t a = lm_ptr[l]; a < lm_ptr[l + 1]; ++ a)
-				row_cnt[obs_pose[a] + 1] += lm_ptr[l + 1] - a; // pairs (a, b >= a)
-		for(int64_t c = 0; c < nc; ++ c)
-			row_cnt[c + 1] += row_cnt[c];
-		std::vector<int32_t> tmp_a(n_pairs), tmp_b(n_pairs);
-		{
-			std::vector<int64_t> fill(row_cnt.begin(), row_cnt.end() - 1);
-			for(int64_t l = 0; l < nl; ++ l)
+		for(int64_t c = 0; c < nc; ++ c) {
+			int64_t sum = row_cnt[c];
+			for(int t = 0; t < nt; ++ t) {
+				const int64_t v = cnt[(size_t)t * nc + c];
+				cnt[(size_t)t * nc + c] = sum; // where chunk t starts in bucket c
+				sum += v;
+			}
+			row_cnt[c + 1] = sum;
+		}
+		clk.lap("pair counts");
+		RawBuf<int32_t> tmp_a, tmp_b, tmp_c; // observation a, observation b, column i2 = pose of b
+		tmp_a.resize(n_pairs);
+		tmp_b.resize(n_pairs);
+		tmp_c.resize(n_pairs);
+		run_threads(nt, [&](int t) {
+			const int64_t b0 = n_pairs * t / nt, b1 = n_pairs * (t + 1) / nt; // first touch, in order
+			memset(tmp_a.p + b0, 0, (size_t)(b1 - b0) * sizeof(int32_t));
+			memset(tmp_b.p + b0, 0, (size_t)(b1 - b0) * sizeof(int32_t));
+			memset(tmp_c.p + b0, 0, (size_t)(b1 - b0) * sizeof(int32_t));
+		});
+		clk.lap("pair buffers");
+		run_threads(nt, [&](int t) {
+			int64_t *fill = cnt.data() + (size_t)t * nc;
+			for(int64_t l = lcut[t]; l < lcut[t + 1]; ++ l)
 				for(int32_t a = lm_ptr[l]; a < lm_ptr[l + 1]; ++ a) {
-					int64_t &f = fill[obs_pose[a]];
+					int64_t f = fill[obs_pose[a]];
+					const int32_t wa = wpos[a];
 					for(int32_t b = a; b < lm_ptr[l + 1]; ++ b) {
-						tmp_a[f] = a;
-						tmp_b[f] = b;
+						tmp_a[f] = wa; // (already the camera-major position the pair lists address)
+						tmp_b[f] = ulm ? b : wpos[b];
+						tmp_c[f] = obs_pose[b];
 						++ f;
 					}
+					fill[obs_pose[a]] = f;
 				}
+		});
+		clk.lap("pairs bucketed by row");
+		// pass 2: rows are independent (row i1 writes the pairs [row_cnt[i1], row_cnt[i1 + 1]))
+		std::vector<int64_t> rcut;
+		{
+			std::vector<int64_t> w(nc + 1, 0);
+			for(int64_t c = 0; c < nc; ++ c)
+				w[c + 1] = w[c] + (row_cnt[c + 1] - row_cnt[c]) + (nc - c); // pairs + the scan over the row's columns
+			balanced_cuts(w, nt, rcut);
 		}
-		// A blocks grouped by row for merging
-		std::vector<std::vector<std::pair<int32_t, int64_t> > > a_by_row(nc);
-		for(size_t q = 0; q < ablk.size(); ++ q)
-			a_by_row[ablk[q].i1].push_back(std::make_pair(ablk[q].i2, ablk[q].off));
-		std::vector<int64_t> col_cnt(nc + 1);
-		std::vector<int64_t> a_of_col(nc);
-		std::vector<char> foreign(nc, 0);
-		int64_t out = 0;
-		for(int64_t i1 = 0; i1 < nc; ++ i1) {
-			const int64_t b0 = row_cnt[i1], b1 = row_cnt[i1 + 1];
-			std::fill(col_cnt.begin(), col_cnt.end(), 0);
-			std::fill(a_of_col.begin() + i1, a_of_col.end(), -1);
-			for(int64_t q = b0; q < b1; ++ q)
-				++ col_cnt[obs_pose[tmp_b[q]] + 1];
-			for(size_t q = 0; q < a_by_row[i1].size(); ++ q)
-				a_of_col[a_by_row[i1][q].first] = a_by_row[i1][q].second;
-			if(!foreign_cols.empty())
-				for(size_t q = 0; q < foreign_cols[i1].size(); ++ q)
-					foreign[foreign_cols[i1][q]] = 1;
-			// blocks of this row, ascending i2
-			std::vector<int64_t> start(nc + 1, 0);
-			for(int64_t c = i1; c < nc; ++ c) {
-				start[c] = out;
-				if(col_cnt[c + 1] || a_of_col[c] >= 0 || foreign[c]) {
-					sblk_i1.push_back((int32_t)i1);
-					sblk_i2.push_back((int32_t)c);
-					sblk_aoff.push_back(a_of_col[c]);
-					sblk_beg.push_back(out);
+		struct RowOut { std::vector<int32_t> i1, i2; std::vector<int64_t> aoff, beg; };
+		std::vector<RowOut> rout(nt);
+		run_threads(nt, [&](int t) {
+			RowOut &ro = rout[t];
+			std::vector<int64_t> col_cnt(nc + 1), a_of_col(nc), start(nc + 1, 0);
+			std::vector<char> foreign(nc, 0);
+			for(int64_t i1 = rcut[t]; i1 < rcut[t + 1]; ++ i1) {
+				const int64_t b0 = row_cnt[i1], b1 = row_cnt[i1 + 1];
+				std::fill(col_cnt.begin() + i1, col_cnt.end(), 0);
+				std::fill(a_of_col.begin() + i1, a_of_col.end(), -1);
+				for(int64_t q = b0; q < b1; ++ q)
+					++ col_cnt[tmp_c[q] + 1];
+				for(size_t q = 0; q < a_by_row[i1].size(); ++ q)
+					a_of_col[a_by_row[i1][q].first] = a_by_row[i1][q].second;
+				if(!foreign_cols.empty())
+					for(size_t q = 0; q < foreign_cols[i1].size(); ++ q)
+						foreign[foreign_cols[i1][q]] = 1;
+				// blocks of this row, ascending i2
+				int64_t out = b0;
+				for(int64_t c = i1; c < nc; ++ c) {
+					start[c] = out;
+					if(col_cnt[c + 1] || a_of_col[c] >= 0 || foreign[c]) {
+						ro.i1.push_back((int32_t)i1);
+						ro.i2.push_back((int32_t)c);
+						ro.aoff.push_back(a_of_col[c]);
+						ro.beg.push_back(out);
+					}
+					out += col_cnt[c + 1];
 				}
-				out += col_cnt[c + 1];
+				if(!foreign_cols.empty())
+					for(size_t q = 0; q < foreign_cols[i1].size(); ++ q)
+						foreign[foreign_cols[i1][q]] = 0;
+				// stable: landmark order preserved. The pair lists address W / Up, i.e. camera-major positions (the packed
+				// U either camera-major like W, or landmark-major = in observation order: the blocks of one landmark's
+				// observers are then one contiguous run, which the blocks of one ROW of S gather together)
+				for(int64_t q = b0; q < b1; ++ q) {
+					int64_t &f = start[tmp_c[q]];
+					pair_a[f] = tmp_a[q];
+					pair_b[f] = tmp_b[q];
+					++ f;
+				}
 			}
-			if(!foreign_cols.empty())
-				for(size_t q = 0; q < foreign_cols[i1].size(); ++ q)
-					foreign[foreign_cols[i1][q]] = 0;
-			for(int64_t q = b0; q < b1; ++ q) { // stable: landmark order preserved
-				int64_t &f = start[obs_pose[tmp_b[q]]];
-				pair_a[f] = tmp_a[q];
-				pair_b[f] = tmp_b[q];
-				++ f;
-			}
+		});
+		clk.lap("rows sorted by column");
+		size_t nblk = 0;
+		for(int t = 0; t < nt; ++ t)
+			nblk += rout[t].i1.size();
+		sblk_i1.reserve(nblk);
+		sblk_i2.reserve(nblk);
+		sblk_aoff.reserve(nblk);
+		sblk_beg.reserve(nblk + 1);
+		for(int t = 0; t < nt; ++ t) {
+			sblk_i1.insert(sblk_i1.end(), rout[t].i1.begin(), rout[t].i1.end());
+			sblk_i2.insert(sblk_i2.end(), rout[t].i2.begin(), rout[t].i2.end());
+			sblk_aoff.insert(sblk_aoff.end(), rout[t].aoff.begin(), rout[t].aoff.end());
+			sblk_beg.insert(sblk_beg.end(), rout[t].beg.begin(), rout[t].beg.end());
 		}
-		sblk_beg.push_back(out);
+		sblk_beg.push_back(n_pairs);
 	}
 	const int64_t n_sblk = (int64_t)sblk_i1.size();
-	sp.n_sblk = n_sblk;
+	h.n_sblk = n_sblk;
 
 	// ---- sparse reduced system: the written blocks of S as an upper block-CSC structure (columns = i2,
 	// rows i1 ascending, diagonal last): the block list above is row-major, a counting sort by column
 	// keeps the rows ascending
-	std::vector<int64_t> sblk_voff_h; // host copy for the item records
 	if(sparse_S) {
-		Structure &ss = sp.s_st;
+		Structure &ss = h.s_st;
 		ss.nb = nc;
 		ss.nnzb = n_sblk;
 		ss.dim.assign(nc, dp);
@@ -361,36 +557,24 @@ void build_schur_plan(spp_ctx *ctx, bool sparse_S, bool mis)
 			ss.col_ptr[c + 1] += ss.col_ptr[c];
 		ss.row_idx.resize(n_sblk);
 		ss.blk_off.resize(n_sblk);
-		std::vector<int64_t> voff(n_sblk), fill(ss.col_ptr.begin(), ss.col_ptr.end() - 1);
+		std::vector<int64_t> fill(ss.col_ptr.begin(), ss.col_ptr.end() - 1);
+		h.sblk_voff.resize(n_sblk);
 		for(int64_t b = 0; b < n_sblk; ++ b) {
 			const int64_t q = fill[sblk_i2[b]] ++;
 			ss.row_idx[q] = sblk_i1[b];
 			ss.blk_off[q] = q * dp * dp;
-			voff[b] = q * dp * dp;
+			h.sblk_voff[b] = q * dp * dp;
 		}
 		ss.nvals = n_sblk * dp * dp;
 		for(int64_t c = 0; c < nc; ++ c)
 			SPP_REQUIRE(ss.col_ptr[c + 1] > ss.col_ptr[c] && ss.row_idx[ss.col_ptr[c + 1] - 1] == c, SPP_E_BADARG,
 				"a pose without any diagonal contribution: the reduced system is singular");
-		sp.sblk_voff.upload(voff, s);
-		sblk_voff_h.swap(voff);
 	}
 
-	// the pair lists address W / Up, i.e. camera-major positions
-	// (the packed U either camera-major like W, or landmark-major = in observation order: the blocks of one
-	// landmark's observers are then one contiguous run, which the blocks of one ROW of S gather together)
-	{
-		const char *e = getenv("SPP_SACC_ULM");
-		sp.u_landmark_major = e ? atoi(e) != 0 : true;
-	}
-	for(int64_t q = 0; q < n_pairs; ++ q) {
-		pair_a[q] = wpos[pair_a[q]];
-		if(!sp.u_landmark_major)
-			pair_b[q] = wpos[pair_b[q]];
-	}
-
+	clk.lap("block lists");
 	// ---- work items: chunks of at most PAIR_CHUNK pairs
-	std::vector<int32_t> item_blk, item_beg, item_end, item_slot, multi_blk, multi_ptr;
+	std::vector<int32_t> item_blk, item_beg, item_end, item_slot;
+	std::vector<int32_t> &multi_blk = h.multi_blk, &multi_ptr = h.multi_ptr;
 	int32_t n_slots = 0;
 	for(int64_t b = 0; b < n_sblk; ++ b) {
 		const int64_t beg = sblk_beg[b], end = sblk_beg[b + 1];
@@ -407,6 +591,7 @@ void build_schur_plan(spp_ctx *ctx, bool sparse_S, bool mis)
 		}
 	}
 	multi_ptr.push_back(n_slots);
+	h.n_slots = n_slots;
 	// Item order = execution order. Blocks are visited tile by tile (SACC_TILE x SACC_TILE cameras):
 	// the W segments of the tile's row cameras and the U segments of its column cameras (~0.5 MB each
 	// on Venice) then stay in the L2 of the XCD that works through the tile (the kernel hands each XCD
@@ -434,7 +619,10 @@ void build_schur_plan(spp_ctx *ctx, bool sparse_S, bool mis)
 			il_env = e ? atoi(e) : 1;
 		}
 		interleave = il_env != 0;
-		auto tile_of = [&](int32_t q) { return (sblk_i1[item_blk[q]] / TB) * ntile + sblk_i2[item_blk[q]] / TBC; };
+		std::vector<int64_t> tile_of_item(item_blk.size());
+		for(size_t q = 0; q < tile_of_item.size(); ++ q)
+			tile_of_item[q] = (sblk_i1[item_blk[q]] / TB) * ntile + sblk_i2[item_blk[q]] / TBC;
+		auto tile_of = [&](int32_t q) { return tile_of_item[q]; };
 		std::stable_sort(perm.begin(), perm.end(), [&](int32_t x, int32_t y) { return tile_of(x) < tile_of(y); });
 		if(interleave) {
 			// All eight XCDs work in the same neighbourhood of S: consecutive tiles (in tile-row-major order) go to
@@ -476,86 +664,127 @@ void build_schur_plan(spp_ctx *ctx, bool sparse_S, bool mis)
 		}
 		item_blk.swap(t_blk); item_beg.swap(t_beg); item_end.swap(t_end); item_slot.swap(t_slot);
 	}
-	sp.n_items = (int64_t)item_blk.size();
+	h.n_items = (int64_t)item_blk.size();
 	// eight item ranges (one per XCD). Contiguous ranges: of equal WORK -- a wave spends a fixed cost per item plus
 	// one gather round per 64 pairs; equal item counts would leave the last range ~45 % heavier
 	{
-		std::vector<int32_t> xb(9, 0);
+		std::vector<int32_t> &xb = h.xb;
+		xb.assign(9, 0);
 		if(interleave)
 			xb = xb_il;
 		else {
-			std::vector<int64_t> cost(sp.n_items + 1, 0);
-			for(int64_t q = 0; q < sp.n_items; ++ q)
+			std::vector<int64_t> cost(h.n_items + 1, 0);
+			for(int64_t q = 0; q < h.n_items; ++ q)
 				cost[q + 1] = cost[q] + 2 + (item_end[q] - item_beg[q] + 63) / 64;
 			for(int x = 1; x < 8; ++ x)
-				xb[x] = (int32_t)(std::lower_bound(cost.begin(), cost.end(), cost[sp.n_items] * x / 8) - cost.begin());
-			xb[8] = (int32_t)sp.n_items;
+				xb[x] = (int32_t)(std::lower_bound(cost.begin(), cost.end(), cost[h.n_items] * x / 8) - cost.begin());
+			xb[8] = (int32_t)h.n_items;
 		}
-		sp.xcd_max_items = 0;
+		h.xcd_max_items = 0;
 		for(int x = 0; x < 8; ++ x) {
 			xb[x + 1] = std::max(xb[x + 1], xb[x]);
-			sp.xcd_max_items = std::max(sp.xcd_max_items, xb[x + 1] - xb[x]);
+			h.xcd_max_items = std::max(h.xcd_max_items, xb[x + 1] - xb[x]);
 		}
-		sp.xcd_beg.upload(xb, s);
 	}
-	sp.n_multi = (int64_t)multi_blk.size();
+	h.n_multi = (int64_t)multi_blk.size();
 
 	// ---- rhs offsets
-	std::vector<int64_t> pose_rbase(nc), lm_rbase(nl);
+	h.pose_rbase.resize(nc);
+	h.lm_rbase.resize(nl);
 	for(int64_t c = 0; c < nc; ++ c)
-		pose_rbase[c] = st.base[sp.pose_block[c]];
+		h.pose_rbase[c] = st.base[h.pose_block[c]];
 	for(int64_t l = 0; l < nl; ++ l)
-		lm_rbase[l] = st.base[sp.lm_block[l]];
+		h.lm_rbase[l] = st.base[h.lm_block[l]];
 
-	// ---- upload
-	sp.lm_ptr.upload(lm_ptr, s);
-	sp.lm_coff.upload(lm_coff, s);
-	sp.lm_rbase.upload(lm_rbase, s);
-	sp.obs_pose.upload(obs_pose, s);
-	sp.obs_lm.upload(obs_lm, s);
-	sp.obs_off.upload(obs_off, s);
-	sp.pose_rbase.upload(pose_rbase, s);
-	sp.cam_ptr.upload(cam_ptr, s);
-	sp.cam_obs.upload(cam_obs, s);
-	{
-		// self-contained item records (one 32-byte load per item in the kernel)
-		std::vector<SaccItem> recs(item_blk.size());
-		for(size_t q = 0; q < recs.size(); ++ q) {
-			const int32_t b = item_blk[q];
-			SaccItem &r = recs[q];
-			r.beg = item_beg[q];
-			r.end = item_end[q];
-			r.pad = 0;
-			r.aoff = -1;
-			if(item_slot[q] >= 0) { // split block: s_multi_kernel sums the slots and adds A
-				r.kind = 2;
-				r.dst = (int64_t)item_slot[q] * dp * dp;
+	clk.lap("work items");
+	// self-contained item records (one 32-byte load per item in the kernel)
+	h.recs.resize(item_blk.size());
+	for(size_t q = 0; q < h.recs.size(); ++ q) {
+		const int32_t b = item_blk[q];
+		SaccItem &r = h.recs[q];
+		r.beg = item_beg[q];
+		r.end = item_end[q];
+		r.pad = 0;
+		r.aoff = -1;
+		if(item_slot[q] >= 0) { // split block: s_multi_kernel sums the slots and adds A
+			r.kind = 2;
+			r.dst = (int64_t)item_slot[q] * dp * dp;
+		} else {
+			r.aoff = add_A ? sblk_aoff[b] : -1;
+			if(sparse_S) {
+				r.kind = 1;
+				r.dst = h.sblk_voff[b];
 			} else {
-				r.aoff = sp.add_A ? sblk_aoff[b] : -1;
-				if(sparse_S) {
-					r.kind = 1;
-					r.dst = sblk_voff_h[b];
-				} else {
-					r.kind = 0;
-					r.dst = (int64_t)sblk_i1[b] * dp + (int64_t)sblk_i2[b] * dp * sp.ld;
-				}
+				r.kind = 0;
+				r.dst = (int64_t)sblk_i1[b] * dp + (int64_t)sblk_i2[b] * dp * h.ld;
 			}
 		}
-		sp.items.upload(recs, s);
 	}
-	sp.obs_wpos.upload(wpos, s);
-	sp.sblk_i1.upload(sblk_i1, s);
-	sp.sblk_i2.upload(sblk_i2, s);
-	sp.sblk_aoff.upload(sblk_aoff, s);
-	sp.pair_a.upload(pair_a, s);
-	sp.pair_b.upload(pair_b, s);
-	sp.multi_blk.upload(multi_blk, s);
-	sp.multi_ptr.upload(multi_ptr, s);
+}
+
+void build_schur_plan(spp_ctx *ctx, bool sparse_S, bool mis)
+{
+	const Structure &st = ctx->st;
+	SchurPlan &sp = ctx->schur;
+	sp.release_all();
+	sp.sparse_S = sparse_S;
+	hipStream_t s = ctx->stream;
+	SchurPlanHost h;
+	schur_plan_host(st, ctx->shard_rank, ctx->shard_world, sparse_S, mis, h);
+	const int dp = h.dp, dl = h.dl;
+	const int64_t nc = h.nc, nl = h.nl, no = h.no;
+	sp.dp = dp;
+	sp.dl = dl;
+	sp.pose_block.swap(h.pose_block);
+	sp.lm_block.swap(h.lm_block);
+	sp.is_lm.swap(h.is_lm);
+	sp.nc = nc;
+	sp.nl = nl;
+	sp.nl_total = h.nl_total;
+	sp.add_A = (ctx->shard_rank == 0);
+	sp.n_red = h.n_red;
+	sp.ld = h.ld;
+	sp.no = no;
+	sp.n_pairs = h.n_pairs;
+	sp.n_sblk = h.n_sblk;
+	sp.u_landmark_major = h.u_landmark_major;
+	sp.n_items = h.n_items;
+	sp.n_multi = h.n_multi;
+	sp.xcd_max_items = h.xcd_max_items;
+	if(sparse_S) {
+		sp.s_st = h.s_st;
+		sp.sblk_voff.upload(h.sblk_voff, s);
+	}
+
+	// ---- upload
+	sp.xcd_beg.upload(h.xb, s);
+	sp.lm_ptr.upload(h.lm_ptr, s);
+	sp.lm_coff.upload(h.lm_coff, s);
+	sp.lm_rbase.upload(h.lm_rbase, s);
+	sp.obs_pose.upload(h.obs_pose, s);
+	sp.obs_lm.upload(h.obs_lm, s);
+	sp.obs_off.upload(h.obs_off, s);
+	sp.pose_rbase.upload(h.pose_rbase, s);
+	sp.cam_ptr.upload(h.cam_ptr, s);
+	sp.cam_obs.upload(h.cam_obs, s);
+	sp.items.upload(h.recs, s);
+	sp.obs_wpos.upload(h.wpos, s);
+	sp.sblk_i1.upload(h.sblk_i1, s);
+	sp.sblk_i2.upload(h.sblk_i2, s);
+	sp.sblk_aoff.upload(h.sblk_aoff, s);
+	sp.pair_a.reserve(std::max<size_t>(1, h.pair_a.size()));
+	sp.pair_b.reserve(std::max<size_t>(1, h.pair_b.size()));
+	if(h.pair_a.size()) {
+		SPP_HIP_CHECK(hipMemcpyAsync(sp.pair_a.p, h.pair_a.p, h.pair_a.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+		SPP_HIP_CHECK(hipMemcpyAsync(sp.pair_b.p, h.pair_b.p, h.pair_b.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+	}
+	sp.multi_blk.upload(h.multi_blk, s);
+	sp.multi_ptr.upload(h.multi_ptr, s);
 	sp.cinv.reserve((size_t)std::max<int64_t>(1, nl) * dl * dl);
 	sp.W.reserve((size_t)std::max<int64_t>(1, no) * dp * dl);
 	sp.Up.reserve((size_t)std::max<int64_t>(1, no) * dp * dl);
 	sp.xw.reserve((size_t)std::max<int64_t>(1, no) * dp);
-	sp.partial.reserve((size_t)std::max<int32_t>(1, n_slots) * dp * dp);
+	sp.partial.reserve((size_t)std::max<int32_t>(1, h.n_slots) * dp * dp);
 	SPP_HIP_CHECK(hipStreamSynchronize(s)); // host vectors die here
 
 	if(!sparse_S)
@@ -566,9 +795,37 @@ void build_schur_plan(spp_ctx *ctx, bool sparse_S, bool mis)
 	ctx->factor_flops = (int64_t)(n * n * n / 3.0 + 2.0 * n * n);
 	ctx->factor_nnz = sp.ld * sp.ld;
 	const int64_t blk_pl = 8 * dp * dl, blk_pp = 8 * dp * dp, blk_ll = 8 * dl * dl;
-	ctx->solve_bytes = blk_pl * no + blk_ll * nl + blk_pp * (int64_t)ablk.size() + 8 * st.n /* read */
-		+ blk_pp * n_sblk + 8 * st.n /* write S, solution */
+	ctx->solve_bytes = blk_pl * no + blk_ll * nl + blk_pp * h.n_ablk + 8 * st.n /* read */
+		+ blk_pp * sp.n_sblk + 8 * st.n /* write S, solution */
 		+ 8 * sp.n_red * sp.n_red /* dense factor touched once in place */;
+}
+
+// host-only: the symbolic Schur plan of a structure, timed; out[0..7] = nc, nl, no, n_pairs, n_sblk, n_items, n_multi,
+// a checksum of the pair lists and block list (tests compare thread counts against each other)
+double schur_plan_host_probe(const Structure &st, int shard_rank, int shard_world, bool sparse_S, int64_t *out)
+{
+	const auto t0 = std::chrono::steady_clock::now();
+	SchurPlanHost h;
+	schur_plan_host(st, shard_rank, shard_world, sparse_S, false, h);
+	const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	uint64_t sum = 1469598103934665603ull;
+	auto mix = [&](uint64_t v) { sum = (sum ^ v) * 1099511628211ull; };
+	for(size_t q = 0; q < h.pair_a.size(); ++ q)
+		mix(((uint64_t)(uint32_t)h.pair_a[q] << 32) | (uint32_t)h.pair_b[q]);
+	for(size_t q = 0; q < h.sblk_i1.size(); ++ q) {
+		mix(((uint64_t)(uint32_t)h.sblk_i1[q] << 32) | (uint32_t)h.sblk_i2[q]);
+		mix((uint64_t)h.sblk_aoff[q]);
+	}
+	for(size_t q = 0; q < h.recs.size(); ++ q) {
+		mix(((uint64_t)(uint32_t)h.recs[q].beg << 32) | (uint32_t)h.recs[q].end);
+		mix((uint64_t)h.recs[q].dst);
+		mix((uint64_t)h.recs[q].aoff + (uint64_t)h.recs[q].kind);
+	}
+	for(size_t q = 0; q < h.xb.size(); ++ q)
+		mix((uint64_t)h.xb[q]);
+	out[0] = h.nc; out[1] = h.nl; out[2] = h.no; out[3] = h.n_pairs; out[4] = h.n_sblk; out[5] = h.n_items; out[6] = h.n_multi;
+	out[7] = (int64_t)sum;
+	return sec;
 }
 
 // --------------------------------------------------------------------------------------------------
