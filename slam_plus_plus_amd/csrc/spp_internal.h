@@ -92,6 +92,7 @@ struct SchurPlan {
 	int64_t n_items = 0, n_multi = 0; // work items (block chunks) / blocks split over several items
 	bool add_A = true;             // this shard adds A and the pose rhs (rank 0)
 	bool u_landmark_major = true;  // layout of the packed U blocks (Up): observation order instead of camera-major
+	bool factored = true;          // S accumulation on ONE packed block per observation, V = U F with C^-1 = F F^T (spp_schur.hip)
 	// reduced camera system kept SPARSE (block-CSC, dp x dp blocks) and solved by the supernodal path:
 	// S buffer = [ s_st.nvals block values | n_red reduced rhs ]
 	bool sparse_S = false;
@@ -125,6 +126,7 @@ struct SchurPlan {
 	DevBuf<int32_t> multi_ptr;     // [n_multi+1] slot range
 	// numeric workspaces
 	DevBuf<double> cinv;           // [nl * dl*dl]   -(C^-1)
+	DevBuf<double> lfac;           // [nl * dl*dl]   F = chol(C)^-T, upper triangular, C^-1 = F F^T (factored form)
 	DevBuf<double> W;              // [no * dp*dl]   -U C^-1, camera-major
 	DevBuf<double> Up;             // [no * dp*dl]   U packed, camera-major
 	DevBuf<double> xw;             // [no * dp]      W l per observation

@@ -30,7 +30,7 @@ namespace spp {
 template <int DL>
 __global__ __launch_bounds__(256)
 void cinv_kernel(int64_t nl, const int64_t *__restrict__ lm_coff, const double *__restrict__ vals,
-	double *__restrict__ cinv)
+	double *__restrict__ cinv, double *__restrict__ lfac)
 {
 	const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if(l >= nl)
@@ -93,6 +93,48 @@ void cinv_kernel(int64_t nl, const int64_t *__restrict__ lm_coff, const double *
 #pragma unroll
 			for(int j = 0; j < DL; ++ j)
 				o[i + DL * j] = -b[i][j];
+	}
+	if(lfac) {
+		// factored operand of the S accumulation: C = G G^T (Cholesky of the block itself, not of its computed inverse),
+		// F = G^-T (upper triangular), C^-1 = F F^T -- so that W U^T = -(U F)(U F)^T needs ONE packed block per observation
+		double G[DL][DL], Gi[DL][DL];
+#pragma unroll
+		for(int j = 0; j < DL; ++ j)
+#pragma unroll
+			for(int i = 0; i < DL; ++ i) {
+				G[i][j] = 0;
+				if(i < j)
+					continue;
+				double sum = m[i + DL * j];
+#pragma unroll
+				for(int t = 0; t < DL; ++ t)
+					if(t < j)
+						sum -= G[i][t] * G[j][t];
+				G[i][j] = (i == j) ? sqrt(sum) : sum / G[j][j];
+			}
+#pragma unroll
+		for(int j = 0; j < DL; ++ j)
+#pragma unroll
+			for(int i = 0; i < DL; ++ i) {
+				Gi[i][j] = 0;
+				if(i < j)
+					continue;
+				if(i == j) {
+					Gi[i][j] = 1.0 / G[j][j];
+					continue;
+				}
+				double sum = 0;
+#pragma unroll
+				for(int t = 0; t < DL; ++ t)
+					if(t >= j && t < i)
+						sum += G[i][t] * Gi[t][j];
+				Gi[i][j] = -sum / G[i][i];
+			}
+#pragma unroll
+		for(int q = 0; q < DL; ++ q)
+#pragma unroll
+			for(int t = 0; t < DL; ++ t)
+				lfac[l * DL * DL + t + DL * q] = Gi[q][t]; // F[t][q] = Ginv[q][t], zero for t > q
 	}
 }
 
@@ -198,6 +240,97 @@ void obs_kernel(int64_t no, const int32_t *__restrict__ obs_lm, const int64_t *_
 	}
 }
 
+// ---- factored form: V = U F (C^-1 = F F^T, F = chol(C)^-T), V t with t = F^T l : one lane per observation ---------------------------
+// One packed block per observation, in OBSERVATION order (landmark-major: the observers of a landmark are one
+// contiguous run, so the two operands of a block product V_a V_b^T lie in the same few cache lines). A DP x DL = 6 x 3
+// block is stored as 16 doubles in a 128-byte-aligned row of Vm + 2 doubles in the side array Vs: a gather pulls ONE
+// line per block (+ a 16-byte piece of a line that eight neighbouring observations share) instead of the two or three
+// lines a 144-byte block straddles. xw = W l = -V (F^T l) stays camera-major (rhs_kernel sums a pose's contiguous list).
+template <int BLK> struct VSplit { static constexpr int IL = (BLK == 18) ? 16 : BLK, SIDE = BLK - IL; };
+
+template <int DP, int DL>
+__global__ __launch_bounds__(256)
+void obs_fact_kernel(int64_t no, const int32_t *__restrict__ obs_lm, const int64_t *__restrict__ obs_off,
+	const int64_t *__restrict__ lm_rbase, const double *__restrict__ vals, const double *__restrict__ rhs,
+	const double *__restrict__ lfac, const int32_t *__restrict__ obs_wpos, double *__restrict__ Vm, double *__restrict__ Vs,
+	double *__restrict__ xw)
+{
+	constexpr int BLK = DP * DL, ST = BLK | 1, IL = VSplit<BLK>::IL, SIDE = VSplit<BLK>::SIDE;
+	__shared__ double img_all[4][64 * ST];
+	__shared__ int32_t slot_all[4][64];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	double *img = img_all[wave];
+	int32_t *slot = slot_all[wave];
+	const int64_t a0 = ((int64_t)blockIdx.x * 4 + wave) * 64, a = a0 + lane;
+	const bool active = a < no;
+	const int nact = (no - a0 < 64) ? (int)((no - a0 > 0) ? (no - a0) : 0) : 64;
+	const int64_t oo = active ? obs_off[a] : 0;
+	const int32_t l = active ? obs_lm[a] : 0;
+	slot[lane] = active ? obs_wpos[a] : 0; // camera-major slot of this observation (xw)
+	double U[BLK];
+	if(active)
+		load_U<DP, DL>(vals, oo, U);
+	else {
+#pragma unroll
+		for(int e = 0; e < BLK; ++ e)
+			U[e] = 0;
+	}
+	double F[DL * DL], lv[DL], tv[DL];
+#pragma unroll
+	for(int e = 0; e < DL * DL; ++ e)
+		F[e] = lfac[(int64_t)l * DL * DL + e];
+#pragma unroll
+	for(int q = 0; q < DL; ++ q)
+		lv[q] = active ? rhs[lm_rbase[l] + q] : 0.0;
+#pragma unroll
+	for(int q = 0; q < DL; ++ q) { // t = F^T l (F upper: t_q = sum_{u <= q} F[u][q] l_u)
+		double sum = 0;
+#pragma unroll
+		for(int u = 0; u < DL; ++ u)
+			if(u <= q)
+				sum += F[u + DL * q] * lv[u];
+		tv[q] = sum;
+	}
+	double V[BLK], Wl[DP];
+#pragma unroll
+	for(int r = 0; r < DP; ++ r)
+		Wl[r] = 0;
+#pragma unroll
+	for(int q = 0; q < DL; ++ q)
+#pragma unroll
+		for(int r = 0; r < DP; ++ r) {
+			double sum = 0;
+#pragma unroll
+			for(int t = 0; t < DL; ++ t)
+				if(t <= q)
+					sum += U[r + DP * t] * F[t + DL * q];
+			V[r + DP * q] = sum;
+			Wl[r] -= sum * tv[q];
+		}
+#pragma unroll
+	for(int e = 0; e < BLK; ++ e)
+		img[lane * ST + e] = V[e];
+	__syncthreads();
+	for(int p = lane; p < nact * IL; p += 64) { // the in-line parts of the wave's 64 blocks are one contiguous range
+		const int j = p / IL, e = p - j * IL;
+		Vm[a0 * IL + p] = img[j * ST + e];
+	}
+	if(SIDE)
+		for(int p = lane; p < nact * SIDE; p += 64) {
+			const int j = p / (SIDE ? SIDE : 1), e = p - j * SIDE;
+			Vs[a0 * SIDE + p] = img[j * ST + IL + e];
+		}
+	__syncthreads();
+#pragma unroll
+	for(int r = 0; r < DP; ++ r)
+		img[lane * (DP | 1) + r] = Wl[r];
+	__syncthreads();
+	for(int p = lane; p < nact * DP; p += 64) {
+		const int j = p / DP, r = p - j * DP;
+		xw[(int64_t)slot[j] * DP + r] = img[j * (DP | 1) + r];
+	}
+}
+
 // ---- S block accumulation: a wave works through a short run of work items ------------------------------
 // Each LANE takes whole pairs (a, b) of the item's list (lane, lane + 64, ...) and forms the DP x DP
 // outer product sum W_a U_b^T in registers (108 FMAs per pair). The blocks are NOT fetched by the lane
@@ -248,7 +381,9 @@ __device__ __forceinline__ SaccItem sacc_load_item(const SaccItem *__restrict__ 
 #ifndef SPP_SACC_EU
 #define SPP_SACC_EU 2 // waves per SIMD the register allocator leaves room for (2: 256 VGPRs; the LDS images allow 8 waves per CU anyway)
 #endif
-template <int DP, int DL>
+// FACT: both operands of a product are packed blocks V of the factored form (obs_fact_kernel): W = the in-line array Vm,
+// Up = the side array Vs, pair_a / pair_b both observation indices; the accumulators collect -V_a V_b^T
+template <int DP, int DL, bool FACT>
 __global__ __launch_bounds__(SACC_WAVES * 64) __attribute__((amdgpu_waves_per_eu(SPP_SACC_EU, SPP_SACC_EU)))
 void s_accum_kernel(const SaccItem *__restrict__ items, const int32_t *__restrict__ xcd_beg, int chunk,
 	const int32_t *__restrict__ pair_a, const int32_t *__restrict__ pair_b,
@@ -256,6 +391,7 @@ void s_accum_kernel(const SaccItem *__restrict__ items, const int32_t *__restric
 	double *__restrict__ S, int64_t ld, double *__restrict__ partial)
 {
 	constexpr int NE = DP * DP, BLK = DP * DL;
+	constexpr int IL = VSplit<BLK>::IL, SIDE = VSplit<BLK>::SIDE;
 	constexpr int PW = (BLK & 1) ? 1 : 2;       // doubles per fetched piece: 16-byte pieces need an even block (9-double
 	                                            // blocks of the 3 x 3 case are only 8-byte aligned: 8-byte pieces)
 	constexpr int PCS = BLK / PW;               // pieces per block
@@ -335,9 +471,18 @@ void s_accum_kernel(const SaccItem *__restrict__ items, const int32_t *__restric
 			for(int g = 0; g < NG; ++ g) {
 				const int p = g * PPI + my_pair;
 				if(my_pair < PPI && p < nround) {
-					__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + (int64_t)ia[g] * BLK + 2 * my_piece),
+					const double *srca, *srcb;
+					if(FACT) { // piece of the in-line row, or of the side array (a lane's piece index is fixed: no divergence inside a block)
+						const bool side = SIDE && 2 * my_piece >= IL;
+						srca = side ? Up + (int64_t)ia[g] * SIDE + (2 * my_piece - IL) : W + (int64_t)ia[g] * IL + 2 * my_piece;
+						srcb = side ? Up + (int64_t)ib[g] * SIDE + (2 * my_piece - IL) : W + (int64_t)ib[g] * IL + 2 * my_piece;
+					} else {
+						srca = W + (int64_t)ia[g] * BLK + 2 * my_piece;
+						srcb = Up + (int64_t)ib[g] * BLK + 2 * my_piece;
+					}
+					__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srca,
 						(__attribute__((address_space(3))) void*)(sw + g * PPI * BLK), 16, 0, 0);
-					__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Up + (int64_t)ib[g] * BLK + 2 * my_piece),
+					__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcb,
 						(__attribute__((address_space(3))) void*)(su + g * PPI * BLK), 16, 0, 0);
 				}
 			}
@@ -362,12 +507,12 @@ void s_accum_kernel(const SaccItem *__restrict__ items, const int32_t *__restric
 				int32_t xa = ia[gg] < 0 ? 0 : ia[gg], xb = ib[gg] < 0 ? 0 : ib[gg];
 				if(PW == 2) {
 					const double2 a2 = *(const double2*)(W + (int64_t)xa * BLK + 2 * my_piece);
-					const double2 b2 = *(const double2*)(Up + (int64_t)xb * BLK + 2 * my_piece);
+					const double2 b2 = *(const double2*)((FACT ? W : Up) + (int64_t)xb * BLK + 2 * my_piece);
 					tw[gg][0] = a2.x; tw[gg][PW - 1] = a2.y;
 					tu[gg][0] = b2.x; tu[gg][PW - 1] = b2.y;
 				} else {
 					tw[gg][0] = W[(int64_t)xa * BLK + my_piece];
-					tu[gg][0] = Up[(int64_t)xb * BLK + my_piece];
+					tu[gg][0] = (FACT ? W : Up)[(int64_t)xb * BLK + my_piece];
 				}
 			}
 #pragma unroll
@@ -424,7 +569,7 @@ void s_accum_kernel(const SaccItem *__restrict__ items, const int32_t *__restric
 #pragma unroll
 					for(int t = 0; t < DL; ++ t)
 						sp += w[r + DP * t] * u[c + DP * t];
-					acc[r + DP * c] += sp;
+					acc[r + DP * c] += FACT ? -sp : sp;
 				}
 #endif
 		}
@@ -670,10 +815,15 @@ static void schur_form_t(spp_ctx *ctx, const double *d_vals, const double *d_rhs
 		SPP_HIP_CHECK(hipMemsetAsync(S + sp.n_red * ld, 0, (size_t)(schur_buffer_doubles(ctx) - sp.n_red * ld) * sizeof(double), s));
 	else
 		SPP_HIP_CHECK(hipMemsetAsync(S, 0, (size_t)schur_buffer_doubles(ctx) * sizeof(double), s));
+	constexpr int VIL = VSplit<DP * DL>::IL;
+	double *Vm = sp.W.p, *Vs = sp.W.p + sp.no * VIL; // factored form: in-line rows, then the side array, in the one buffer W
 	if(sp.nl)
 		hipLaunchKernelGGL((cinv_kernel<DL>), dim3((unsigned)((sp.nl + 255) / 256)), dim3(256), 0, s,
-			sp.nl, sp.lm_coff.p, d_vals, sp.cinv.p);
-	if(sp.no)
+			sp.nl, sp.lm_coff.p, d_vals, sp.cinv.p, sp.factored ? sp.lfac.p : nullptr);
+	if(sp.no && sp.factored)
+		hipLaunchKernelGGL((obs_fact_kernel<DP, DL>), dim3((unsigned)((sp.no + 255) / 256)), dim3(256), 0, s,
+			sp.no, sp.obs_lm.p, sp.obs_off.p, sp.lm_rbase.p, d_vals, d_rhs, sp.lfac.p, sp.obs_wpos.p, Vm, Vs, sp.xw.p);
+	else if(sp.no)
 		hipLaunchKernelGGL((obs_kernel<DP, DL>), dim3((unsigned)((sp.no + 255) / 256)), dim3(256), 0, s,
 			sp.no, sp.obs_lm.p, sp.obs_off.p, sp.lm_rbase.p, d_vals, d_rhs, sp.cinv.p, sp.obs_wpos.p, sp.W.p, sp.Up.p, sp.xw.p, sp.u_landmark_major ? 1 : 0);
 	phase_end(ctx, SPP_PHASE_SCHUR_INV);
@@ -691,8 +841,12 @@ static void schur_form_t(spp_ctx *ctx, const double *d_vals, const double *d_rhs
 		if(chunk <= 0) // persistent: two workgroups per CU (the LDS images of 8 waves fill a CU)
 			chunk = (int)((sp.xcd_max_items + SACC_WAVES * 64 - 1) / (SACC_WAVES * 64));
 		const int64_t per = (int64_t)SACC_WAVES * chunk;
-		hipLaunchKernelGGL((s_accum_kernel<DP, DL>), dim3((unsigned)(8 * ((sp.xcd_max_items + per - 1) / per))), dim3(SACC_WAVES * 64), 0, s,
-			sp.items.p, sp.xcd_beg.p, chunk, sp.pair_a.p, sp.pair_b.p, sp.W.p, sp.Up.p, d_vals, S, ld, sp.partial.p);
+		if(sp.factored)
+			hipLaunchKernelGGL((s_accum_kernel<DP, DL, true>), dim3((unsigned)(8 * ((sp.xcd_max_items + per - 1) / per))), dim3(SACC_WAVES * 64), 0, s,
+				sp.items.p, sp.xcd_beg.p, chunk, sp.pair_a.p, sp.pair_b.p, Vm, Vs, d_vals, S, ld, sp.partial.p);
+		else
+			hipLaunchKernelGGL((s_accum_kernel<DP, DL, false>), dim3((unsigned)(8 * ((sp.xcd_max_items + per - 1) / per))), dim3(SACC_WAVES * 64), 0, s,
+				sp.items.p, sp.xcd_beg.p, chunk, sp.pair_a.p, sp.pair_b.p, sp.W.p, sp.Up.p, d_vals, S, ld, sp.partial.p);
 	}
 	if(sp.n_multi)
 		hipLaunchKernelGGL((s_multi_kernel<DP>), dim3((unsigned)((sp.n_multi + 3) / 4)), dim3(256), 0, s,

@@ -30,7 +30,7 @@ void SchurPlan::release_all()
 	obs_off.release(); pose_rbase.release(); cam_ptr.release(); cam_obs.release(); items.release();
 	obs_wpos.release(); xcd_beg.release(); sblk_i1.release(); sblk_i2.release(); sblk_aoff.release();
 	sblk_voff.release(); s_st = Structure(); sparse_S = false; mis = false;
-	pair_a.release(); pair_b.release(); multi_blk.release(); multi_ptr.release(); cinv.release();
+	pair_a.release(); pair_b.release(); multi_blk.release(); multi_ptr.release(); cinv.release(); lfac.release();
 	W.release(); Up.release(); xw.release(); partial.release(); S.release();
 	pose_block.clear(); lm_block.clear(); is_lm.clear();
 }
@@ -195,7 +195,7 @@ struct SchurPlanHost {
 	int dp = 0, dl = 0;
 	int64_t nc = 0, nl = 0, nl_total = 0, no = 0, n_red = 0, ld = 0, n_sblk = 0, n_pairs = 0, n_items = 0, n_multi = 0, n_ablk = 0;
 	int32_t n_slots = 0, xcd_max_items = 0;
-	bool u_landmark_major = true;
+	bool u_landmark_major = true, factored = true;
 	std::vector<int64_t> pose_block, lm_block;
 	std::vector<uint8_t> is_lm;
 	std::vector<int32_t> lm_ptr, obs_pose, obs_lm, cam_ptr, cam_obs, wpos, sblk_i1, sblk_i2, multi_blk, multi_ptr, xb;
@@ -395,6 +395,8 @@ static void schur_plan_host(const Structure &st, int shard_rank, int shard_world
 	{
 		const char *e = getenv("SPP_SACC_ULM");
 		h.u_landmark_major = e ? atoi(e) != 0 : true;
+		e = getenv("SPP_SACC_FACTORED"); // 0: two packed blocks per observation (W and U), as in rounds 1-2
+		h.factored = e ? atoi(e) != 0 : true;
 	}
 	RawBuf<int32_t> &pair_a = h.pair_a, &pair_b = h.pair_b;
 	pair_a.resize(n_pairs);
@@ -414,7 +416,7 @@ static void schur_plan_host(const Structure &st, int shard_rank, int shard_world
 	std::vector<int64_t> &sblk_aoff = h.sblk_aoff;
 	std::vector<int64_t> sblk_beg; // pair range per S block
 	const int nt = plan_threads(n_pairs);
-	const bool ulm = h.u_landmark_major;
+	const bool ulm = h.u_landmark_major, fact = h.factored;
 	std::vector<int64_t> lcut;
 	balanced_cuts(lm_pairs, nt, lcut);
 	// A blocks grouped by row for merging
@@ -457,10 +459,10 @@ static void schur_plan_host(const Structure &st, int shard_rank, int shard_world
 			for(int64_t l = lcut[t]; l < lcut[t + 1]; ++ l)
 				for(int32_t a = lm_ptr[l]; a < lm_ptr[l + 1]; ++ a) {
 					int64_t f = fill[obs_pose[a]];
-					const int32_t wa = wpos[a];
+					const int32_t wa = fact ? a : wpos[a];
 					for(int32_t b = a; b < lm_ptr[l + 1]; ++ b) {
-						tmp_a[f] = wa; // (already the camera-major position the pair lists address)
-						tmp_b[f] = ulm ? b : wpos[b];
+						tmp_a[f] = wa; // (already the position the pair lists address: observation order in the factored form, else camera-major)
+						tmp_b[f] = (ulm || fact) ? b : wpos[b];
 						tmp_c[f] = obs_pose[b];
 						++ f;
 					}
@@ -748,6 +750,7 @@ void build_schur_plan(spp_ctx *ctx, bool sparse_S, bool mis)
 	sp.n_pairs = h.n_pairs;
 	sp.n_sblk = h.n_sblk;
 	sp.u_landmark_major = h.u_landmark_major;
+	sp.factored = h.factored;
 	sp.n_items = h.n_items;
 	sp.n_multi = h.n_multi;
 	sp.xcd_max_items = h.xcd_max_items;
@@ -782,7 +785,10 @@ void build_schur_plan(spp_ctx *ctx, bool sparse_S, bool mis)
 	sp.multi_ptr.upload(h.multi_ptr, s);
 	sp.cinv.reserve((size_t)std::max<int64_t>(1, nl) * dl * dl);
 	sp.W.reserve((size_t)std::max<int64_t>(1, no) * dp * dl);
-	sp.Up.reserve((size_t)std::max<int64_t>(1, no) * dp * dl);
+	if(sp.factored)
+		sp.lfac.reserve((size_t)std::max<int64_t>(1, nl) * dl * dl);
+	else
+		sp.Up.reserve((size_t)std::max<int64_t>(1, no) * dp * dl);
 	sp.xw.reserve((size_t)std::max<int64_t>(1, no) * dp);
 	sp.partial.reserve((size_t)std::max<int32_t>(1, h.n_slots) * dp * dp);
 	SPP_HIP_CHECK(hipStreamSynchronize(s)); // host vectors die here
