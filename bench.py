@@ -64,13 +64,16 @@ def main():
                          "weak = every rank brings its own Venice-sized landmark set seen by the same 871 cameras")
     ap.add_argument("--graph", default=None, help="take the workload from a graph file (EDGE_SE2 / EDGE3[:AXISANGLE] / "
                     "VERTEX_CAM + VERTEX_XYZ + EDGE_PROJECT_P2MC) instead of the synthetic generator")
-    ap.add_argument("--cpu-cholmod", default="sample", choices=["sample", "full", "off"],
+    ap.add_argument("--cpu-cholmod", default="auto", choices=["auto", "sample", "full", "off"],
                     help="north_star's CPU path (CLinearSolver_CholMod) timed in this run: on the whole Lambda when that takes "
                          "seconds (pose graphs, Ladybug), on a quarter of the landmarks for the Venice shape (~12 s; the whole "
                          "Lambda takes ~150 s: --cpu-cholmod full)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank path on a single GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0")
+    ap.add_argument("--collective", default="direct", choices=["direct", "allreduce"],
+                    help="N > 1: direct = reduce-scatter by one all-to-all over the point-to-point xGMI links + local sum + "
+                         "all-gather; allreduce = one RCCL all_reduce (ring)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -126,6 +129,9 @@ def main():
     if use_torch_stream:
         torch.cuda.set_stream(torch.cuda.Stream())
 
+    # N > 1: how the packed partial systems are summed (see Job.reduce_packed)
+    collective = ["direct" if (world > 1 and args.backend == "nccl" and args.collective == "direct") else "allreduce"]
+
     class Job:
         """one Lambda resident in HBM + everything a numeric solve needs; shard = (rank, world) of the landmark sharding"""
         def __init__(self, prob, shard, flags):
@@ -151,7 +157,32 @@ def main():
             self.S = self.P = None
             if self.schur and world > 1:
                 self.S = torch.empty(ctx.schur_buffer_size(), dtype=torch.float64, device="cuda")
-                self.P = torch.empty(ctx.schur_packed_size(), dtype=torch.float64, device="cuda")  # upper trapezoid only
+                npk = ctx.schur_packed_size()
+                npad = (npk + world - 1) // world * world  # equal slices for the direct exchange (the tail is zero)
+                self.Pfull = torch.zeros(npad, dtype=torch.float64, device="cuda")
+                self.P = self.Pfull  # upper trapezoid only (+ padding)
+                self.Precv = torch.empty(npad, dtype=torch.float64, device="cuda")
+                self.Pown = torch.empty(npad // world, dtype=torch.float64, device="cuda")
+
+        def reduce_packed(self):
+            """Sum of the ranks' packed partial systems, the result on every rank. xGMI is point to point (7 links per GPU):
+            `direct` = reduce-scatter as ONE all-to-all (every rank sends slice j of its buffer to rank j over their own
+            link: 1/N of the buffer per link, all links at once), a local in-order sum of the N slices, an all-gather of the
+            summed slices -- 2 x (buffer / N) per link instead of the ring all-reduce's 2 (N-1)/N x buffer over one.
+            Deterministic: slice j is summed in rank order on rank j. Falls back to all_reduce (gloo has no all-to-all)."""
+            P = self.P
+            if collective[0] == "direct":
+                try:
+                    n = P.numel() // world
+                    torch.cuda.current_stream()  # (collectives are ordered against the current stream)
+                    dist.all_to_all_single(self.Precv, P)
+                    torch.sum(self.Precv.view(world, n), dim=0, out=self.Pown)
+                    dist.all_gather_into_tensor(P, self.Pown)
+                    return
+                except Exception as e:  # noqa: BLE001 -- never take the measurement down: ring all-reduce instead
+                    collective[0] = "allreduce"
+                    collective.append("direct exchange failed (%r): ring all-reduce" % (e,))
+            dist.all_reduce(P)
 
         def assemble(self):
             d = self.d_in
@@ -167,7 +198,7 @@ def main():
                 ctx.schur_pack(self.S.data_ptr(), self.P.data_ptr())
                 if not use_torch_stream:
                     ctx.synchronize()
-                dist.all_reduce(self.P)       # the one data-path collective: reduced camera system + reduced rhs
+                self.reduce_packed()          # the one data-path exchange: reduced camera system + reduced rhs
                 if not use_torch_stream:
                     torch.cuda.synchronize()
                 ctx.schur_unpack(self.P.data_ptr(), self.S.data_ptr())
@@ -240,74 +271,65 @@ def main():
     # in the reference's parameterization (spp_ba_linearize_device), assembly, solve, ||dx|| and the
     # vertex update (spp_ba_update_device); the state is reset from a device copy every iteration so that
     # all iterations do the same work. Host traffic per iteration: 8 bytes.
-    resident = None
-    if world == 1 and "geometry" in prob and prob.geometry.get("kind") in ("se2", "se3"):
-        # pose graphs: spp_se2_/se3_linearize_device + assembly + sparse solve + ||dx|| + vertex update
-        pg = synth.pose_graph_states(prob)
-        dof, nv_, ne_ = pg["dof"], pg["poses"].shape[0], pg["v0"].size
-        d_pg = {k: api.DeviceArray.from_host(ctx, np.ascontiguousarray(pg[k]).ravel()) for k in ("poses", "meas", "v0", "v1")}
-        d_pw = api.DeviceArray(ctx, pg["poses"].size)
-        r_J0, r_J1, r_r = api.DeviceArray(ctx, d_in[0].n), api.DeviceArray(ctx, d_in[1].n), api.DeviceArray(ctx, d_in[3].n)
-        r_vals, r_eta = api.DeviceArray(ctx, st.nvals), api.DeviceArray(ctx, st.n)
-        lin = ctx.se2_linearize_device if dof == 3 else ctx.se3_linearize_device
-        upd = ctx.se2_update_device if dof == 3 else ctx.se3_update_device
+    # builds the device-resident Gauss-Newton / LM iteration for a ctx: returns (iterate(reset), what, linearize-only fn or None)
+    host_state = None
+    if world == 1 and "geometry" in prob:  # the graph's state in host memory (generated once, outside every clock)
+        host_state = synth.pose_graph_states(prob) if prob.geometry.get("kind") in ("se2", "se3") else synth.ba_states(prob)
 
-        def gn_resident():
-            marks = [time.perf_counter()] if os.environ.get("BENCH_DEBUG") else None
-            d_pw.copy_from(d_pg["poses"])
-            if marks: marks.append(time.perf_counter())
-            lin(ne_, d_pg["v0"].ptr, d_pg["v1"].ptr, d_pw.ptr, d_pg["meas"].ptr, r_J0.ptr, r_J1.ptr, r_r.ptr)
-            if marks: marks.append(time.perf_counter())
-            ctx.assemble_device(r_J0.ptr, r_J1.ptr, d_in[2].ptr, r_r.ptr, 0.0, r_vals.ptr, r_eta.ptr)
-            if marks: marks.append(time.perf_counter())
-            code = ctx.factor_solve_device(r_vals.ptr, r_eta.ptr)
-            if marks: marks.append(time.perf_counter())
-            if code != 0:
-                raise SystemExit("resident GN: factorization failed")
-            out = upd(nv_, d_pw.ptr, r_eta.ptr, apply=True)
-            if marks:
-                marks.append(time.perf_counter())
-                if marks[-1] - marks[0] > 5e-3:  # where a stalled iteration spent its time (host clock per API call)
-                    print("stalled iteration: copy %.3f linearize %.3f assemble %.3f factor_solve %.3f update+norm %.3f ms" % tuple(
-                        1e3 * (b - a) for a, b in zip(marks[:-1], marks[1:])), file=sys.stderr)
-            return out
+    def build_resident(ctx_, st_):
+        d_Om = api.DeviceArray.from_host(ctx_, prob.Om.ravel())
+        r_J0, r_J1, r_r = api.DeviceArray(ctx_, prob.J0.size), api.DeviceArray(ctx_, prob.J1.size), api.DeviceArray(ctx_, prob.r.size)
+        r_vals, r_eta = api.DeviceArray(ctx_, st_.nvals), api.DeviceArray(ctx_, st_.n)
+        if prob.geometry.get("kind") in ("se2", "se3"):
+            # pose graphs: spp_se2_/se3_linearize_device + assembly + sparse solve + ||dx|| + vertex update
+            pg = host_state
+            dof, nv_, ne_ = pg["dof"], pg["poses"].shape[0], pg["v0"].size
+            d_pg = {k: api.DeviceArray.from_host(ctx_, np.ascontiguousarray(pg[k]).ravel()) for k in ("poses", "meas", "v0", "v1")}
+            d_pw = api.DeviceArray(ctx_, pg["poses"].size)
+            lin = ctx_.se2_linearize_device if dof == 3 else ctx_.se3_linearize_device
+            upd = ctx_.se2_update_device if dof == 3 else ctx_.se3_update_device
 
-        ctx.set_profiling(False)
-        for _ in range(2):
-            gn_resident()
-        ctx.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(gn_steps):
-            t1 = time.perf_counter()
-            dxn = gn_resident()
-            if os.environ.get("BENCH_DEBUG"):
-                print("resident iteration %.3f ms" % (1e3 * (time.perf_counter() - t1)), file=sys.stderr)
-        ctx.synchronize()
-        dt_res = time.perf_counter() - t0
-        resident = {"iters_per_s": gn_steps / dt_res, "ms_per_iter": 1e3 * dt_res / gn_steps, "dx_norm": dxn,
-                    "batch_of_5_iterations_ms": 5e3 * dt_res / gn_steps,
-                    "what": "device linearization (CEdgePose%dD, analytic) + assembly + sparse multifrontal solve + ||dx|| + "
-                            "vertex update, everything resident in HBM; state reset by one device copy per iteration (included)" % (2 if dof == 3 else 3)}
-    elif world == 1 and "geometry" in prob:
-        sc = synth.ba_states(prob)
-        d_s = {k: api.DeviceArray.from_host(ctx, np.ascontiguousarray(v).ravel()) for k, v in sc.items()}
-        d_cw, d_pw = api.DeviceArray(ctx, sc["cams"].size), api.DeviceArray(ctx, sc["points"].size)
+            def iterate(reset=True):
+                if reset:
+                    d_pw.copy_from(d_pg["poses"])
+                lin(ne_, d_pg["v0"].ptr, d_pg["v1"].ptr, d_pw.ptr, d_pg["meas"].ptr, r_J0.ptr, r_J1.ptr, r_r.ptr)
+                ctx_.assemble_device(r_J0.ptr, r_J1.ptr, d_Om.ptr, r_r.ptr, 0.0, r_vals.ptr, r_eta.ptr)
+                if ctx_.factor_solve_device(r_vals.ptr, r_eta.ptr) != 0:
+                    raise SystemExit("resident GN: factorization failed")
+                return upd(nv_, d_pw.ptr, r_eta.ptr, apply=True)
+            what = ("device linearization (CEdgePose%dD, analytic) + assembly + sparse multifrontal solve + ||dx|| + vertex update, "
+                    "everything resident in HBM; state reset by one device copy per iteration (included)" % (2 if dof == 3 else 3))
+            return iterate, what, None
+        sc = host_state
+        d_s = {k: api.DeviceArray.from_host(ctx_, np.ascontiguousarray(v).ravel()) for k, v in sc.items()}
+        d_cw, d_pw = api.DeviceArray(ctx_, sc["cams"].size), api.DeviceArray(ctx_, sc["points"].size)
         no_, nc_, np_ = prob.v0.size, sc["cams"].shape[0], sc["points"].shape[0]
-        # own buffers: the Lambda of the timed solves stays intact for the CPU baseline comparison below
-        r_J0, r_J1, r_r = api.DeviceArray(ctx, d_in[0].n), api.DeviceArray(ctx, d_in[1].n), api.DeviceArray(ctx, d_in[3].n)
-        r_vals, r_eta = api.DeviceArray(ctx, st.nvals), api.DeviceArray(ctx, st.n)
 
-        def gn_resident():
-            d_cw.copy_from(d_s["cams"])
-            d_pw.copy_from(d_s["points"])
-            ctx.ba_linearize_device(no_, d_s["cam_of"].ptr, d_s["pt_of"].ptr, d_cw.ptr, d_s["intr"].ptr, d_pw.ptr,
-                                    d_s["meas"].ptr, r_J0.ptr, r_J1.ptr, r_r.ptr)
-            ctx.assemble_device(r_J0.ptr, r_J1.ptr, d_in[2].ptr, r_r.ptr, prob.damping, r_vals.ptr, r_eta.ptr)
-            if ctx.factor_solve_device(r_vals.ptr, r_eta.ptr) != 0:
+        def linearize():
+            ctx_.ba_linearize_device(no_, d_s["cam_of"].ptr, d_s["pt_of"].ptr, d_cw.ptr, d_s["intr"].ptr, d_pw.ptr,
+                                     d_s["meas"].ptr, r_J0.ptr, r_J1.ptr, r_r.ptr)
+
+        def iterate(reset=True):
+            if reset:
+                d_cw.copy_from(d_s["cams"])
+                d_pw.copy_from(d_s["points"])
+            linearize()
+            ctx_.assemble_device(r_J0.ptr, r_J1.ptr, d_Om.ptr, r_r.ptr, prob.damping, r_vals.ptr, r_eta.ptr)
+            if ctx_.factor_solve_device(r_vals.ptr, r_eta.ptr) != 0:
                 raise SystemExit("resident GN: factorization failed")
-            return ctx.ba_update_device(nc_, d_cw.ptr, d_s["cam_dxoff"].ptr, np_, d_pw.ptr, d_s["pt_dxoff"].ptr,
-                                        r_eta.ptr, st.n, apply=True)
+            return ctx_.ba_update_device(nc_, d_cw.ptr, d_s["cam_dxoff"].ptr, np_, d_pw.ptr, d_s["pt_dxoff"].ptr,
+                                         r_eta.ptr, st_.n, apply=True)
+        what = ("device linearization (CEdgeP2C3D, analytic) + assembly + Schur solve + ||dx|| + vertex update; "
+                "state reset by two device copies per iteration (included)")
+        return iterate, what, linearize
 
+    # ---- third loop (one GPU): the whole (damped) Gauss-Newton iteration in HBM -- device linearization in the
+    # reference's parameterization, assembly, solve, ||dx|| and the vertex update; the state is reset from a device copy
+    # every iteration so that all iterations do the same work. Host traffic per iteration: 8 bytes.
+    resident = None
+    batch5 = None
+    if world == 1 and "geometry" in prob:
+        gn_resident, what, linearize = build_resident(ctx, st)
         ctx.set_profiling(False)
         for _ in range(2):
             gn_resident()
@@ -320,17 +342,44 @@ def main():
                 print("resident iteration %.3f ms" % (1e3 * (time.perf_counter() - t1)), file=sys.stderr)
         ctx.synchronize()
         dt_res = time.perf_counter() - t0
-        # the linearization kernel alone (hipEvent-free: wall clock around a synchronized burst)
-        t0 = time.perf_counter()
-        for _ in range(5):
-            ctx.ba_linearize_device(no_, d_s["cam_of"].ptr, d_s["pt_of"].ptr, d_cw.ptr, d_s["intr"].ptr, d_pw.ptr,
-                                    d_s["meas"].ptr, r_J0.ptr, r_J1.ptr, r_r.ptr)
-        ctx.synchronize()
-        lin_ms = 1e3 * (time.perf_counter() - t0) / 5
-        resident = {"iters_per_s": gn_steps / dt_res, "ms_per_iter": 1e3 * dt_res / gn_steps, "linearize_ms": lin_ms,
-                    "linearize_gbs": (no_ * (160 + 16 + 8) + 0.0) / (lin_ms * 1e-3) * 1e-9, "dx_norm": dxn,
-                    "what": "device linearization (CEdgeP2C3D, analytic) + assembly + Schur solve + ||dx|| + vertex update; "
-                            "state reset by two device copies per iteration (included)"}
+        resident = {"iters_per_s": gn_steps / dt_res, "ms_per_iter": 1e3 * dt_res / gn_steps, "dx_norm": dxn, "what": what}
+        if linearize is not None:
+            # the linearization kernel alone (hipEvent-free: wall clock around a synchronized burst)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                linearize()
+            ctx.synchronize()
+            lin_ms = 1e3 * (time.perf_counter() - t0) / 5
+            resident["linearize_ms"] = lin_ms
+            resident["linearize_gbs"] = (prob.v0.size * (160 + 16 + 8) + 0.0) / (lin_ms * 1e-3) * 1e-9
+        # ---- SURVEY 8d metric 2: the batch of 5 iterations END TO END on a fresh context, analysis included -- what the
+        # reference's Optimize() does once per batch (symbolic once, LinearSolver_UberBlock.h:317-320; 5 iterations,
+        # src/slam_app/Main.cpp:706-707; yardstick scripts/tests/unit_tests.sh:50-56). Host arrays (graph, Jacobian inputs) in
+        # host memory when the clock starts; the process-wide one-time set-up (code objects, stream self-tests) is warm.
+        try:
+            t0 = time.perf_counter()
+            c5 = api.Context(local_rank, 0)
+            t1 = time.perf_counter()
+            st5 = c5.assemble_analyze(prob.dim, prob.v0, prob.v1, prob.d0, prob.d1, prob.rd, prob.unary_vertex)
+            t2 = time.perf_counter()
+            c5.analyze(st5, api.MODE_AUTO)
+            t3 = time.perf_counter()
+            it5, _, _ = build_resident(c5, st5)
+            c5.synchronize()
+            t4 = time.perf_counter()
+            for i in range(5):
+                dx5 = it5(reset=(i == 0))
+            c5.synchronize()
+            t5 = time.perf_counter()
+            batch5 = {"total_ms": 1e3 * (t5 - t0), "context_ms": 1e3 * (t1 - t0), "assemble_analyze_ms": 1e3 * (t2 - t1),
+                      "analyze_ms": 1e3 * (t3 - t2), "upload_state_ms": 1e3 * (t4 - t3), "five_iterations_ms": 1e3 * (t5 - t4),
+                      "last_dx_norm": dx5,
+                      "what": "fresh context: Lambda structure + assembly plan from the graph (spp_assemble_analyze), symbolic analysis "
+                              "(spp_analyze: ordering / supernodes or the Schur plan), upload of the graph state, then 5 resident "
+                              "iterations (linearize, assemble, solve, update), end to end"}
+            c5.close()
+        except Exception as e:  # noqa: BLE001
+            batch5 = {"failed": repr(e)}
 
     # ---- N > 1, strong headline: the weak-scaling variant as an extra field (its own problem per rank, own ctx)
     weak_extra = None
@@ -383,10 +432,30 @@ def main():
     }
     if world == 1:
         out["scaling_note"] = "one GPU: the whole problem (strong and weak coincide)"
+    if schur:
+        # what the run's own phase times predict for N GPUs of one node (strong scaling of THIS problem): the dense factor and
+        # the triangular solves are replicated, the landmark phases divide, the exchange moves the packed reduced system
+        # (direct: 1/N of it per point-to-point xGMI link each way, 153 GB/s per link -- MI355X guide; ring: 2 (N-1)/N of it
+        # over one link). To be read against the driver's SCALE record.
+        rep = phase["factor"] + phase["trisolve"]
+        shard = (phase["schur_inv"] + phase["schur_gemm"] + phase["schur_rhs"] + phase["backsubst"]) * (world if world > 1 else 1)
+        try:
+            pk_bytes = 8.0 * ctx.schur_packed_size()
+        except Exception:  # noqa: BLE001
+            pk_bytes = 0.0
+        link, lat_ms = 153e9, 0.03
+        model = {"replicated_ms": rep, "sharded_ms_on_one_gpu": shard, "exchange_mb": pk_bytes * 1e-6, "per_link_gbs": 153.0,
+                 "predicted_ms_direct": {}, "predicted_ms_ring": {}, "one_gpu_ms": rep + shard}
+        for n_ in (2, 4, 8):
+            model["predicted_ms_direct"][str(n_)] = rep + shard / n_ + 2e3 * (pk_bytes / n_) / link + 2 * lat_ms
+            model["predicted_ms_ring"][str(n_)] = rep + shard / n_ + 2e3 * (n_ - 1) / n_ * pk_bytes / link + lat_ms
+        out["scaling_model"] = model
     if weak_extra is not None:
         out["weak_scaling"] = weak_extra
     if resident is not None:
         out["gn_resident"] = resident
+    if batch5 is not None:
+        out["batch5_wall_ms"] = batch5
 
     # ---- HBM counter traffic of the dominant kernel: a rocprofv3 --pmc run of an EARLIER round (separate passes, the
     # guide's corrections), not of this run; the source file is named beside the number
@@ -468,6 +537,13 @@ def main():
                                "algorithmic_bytes": sbytes, "factor_flops": fflops, "ms": fs_ms,
                                "mfma_frac": fflops / (max(phase["factor"], 1e-9) * 1e-3) * 1e-12 / PEAK_FP64_MFMA_TFLOPS,
                                "tree_levels": int(ctx.info("N_LEVELS")), "supernodes": int(ctx.info("N_SUPERNODES")),
+                               "critical_path": {"levels": int(ctx.info("N_LEVELS")),
+                                                 "factor_us_per_level": 1e3 * phase["factor"] / max(1, int(ctx.info("N_LEVELS"))),
+                                                 "backward_us_per_level": 1e3 * phase["trisolve"] / max(1, int(ctx.info("N_LEVELS"))),
+                                                 "what": "the dependency-driven launches are bound by the heaviest root-to-leaf chain of "
+                                                         "fronts: time / tree levels = what one front of that chain costs (extend-add, "
+                                                         "16-pivot panels at ~240 cycles per pivot, write-back, flag hand-off); "
+                                                         "SPP_DAG_TRACE prints the chain front by front"},
                                "note": "LATENCY-bound, not bandwidth-bound: a few MB of factor whose critical path is the heaviest "
                                        "root-to-leaf chain of fronts over %d tree levels; neither roofline is approached at this "
                                        "size (SURVEY 7.3, 8d)" % int(ctx.info("N_LEVELS"))}
@@ -526,7 +602,7 @@ def main():
                 # ---- north_star's CPU path: CLinearSolver_CholMod (src/slam/LinearSolver_CholMod.cpp:264-358: analyze + factorize
                 # + solve on the whole Lambda, no Schur complement, analysis redone every call), same box, same run
                 if args.cpu_cholmod != "off" and backend != "cholmod":
-                    full = args.cpu_cholmod == "full" or not schur or nnzb <= 200000
+                    full = args.cpu_cholmod in ("full", "auto") or not schur or nnzb <= 200000
                     if full:
                         code, xc, sec = orc.RefSolver("cholmod", lam).solve(lam.vals, eta)
                         out["cpu_baseline"]["cholmod"] = {
@@ -555,6 +631,35 @@ def main():
                                        "sample": "oracle/_ref/libspp_ref.so not present"}
         except Exception as e:  # the baseline must never take the measurement down
             out["cpu_baseline"] = {"value": None, "unit": "block-nnz/s", "cores": 1, "kind": "reference", "sample": "failed: %r" % (e,)}
+    elif not args.no_cpu_baseline and world == 1 and args.cpu_cholmod != "off":
+        # BASELINE config 5 shape: the reference's Schur path is dense (60 000^2 does not fit it), its CHOLMOD path takes
+        # minutes on the whole Lambda: a bounded sample of the SAME generator (1/8 of the cameras, points and observations,
+        # the same ~5-camera co-visibility window), assembled by the HIP kernels in a second ctx
+        try:
+            from oracle import spp_oracle as orc
+            if orc.have_ref() and "nc" in prob:
+                f = 8
+                ps = synth.ba_problem(prob.nc // f, prob.npts // f, prob.v0.size // f, 10000, heavy_tail=False,
+                                      spread=0.0005 * f, name="%s_eighth" % args.workload)
+                js = Job(ps, (0, 1), 0)
+                lam_s, eta_s = js.st.with_vals(js.d_vals.download()), js.d_eta.download()
+                js.solve()
+                xs = js.d_rhs.download()
+                t_gpu = js.timed(5, 1) / 5
+                del js
+                code, xc, sec = orc.RefSolver("cholmod", lam_s).solve(lam_s.vals, eta_s)
+                out["cpu_baseline"] = {
+                    "value": lam_s.nnzb / sec, "unit": "block-nnz/s", "cores": 1, "kind": "reference", "seconds": sec,
+                    "sample": "one Lambda-solve by the reference's CLinearSolver_CholMod of a 1/8-size sample of the workload (same "
+                              "generator and co-visibility window: %d cameras, %d points, %d observations, %d upper blocks); the "
+                              "reference's Schur path is dense and does not fit the full 60 000-wide reduced system" % (
+                                  ps.nc, ps.npts, ps.v0.size, lam_s.nnzb),
+                    "gpu_ms_on_the_same_sample": 1e3 * t_gpu,
+                    "rel_diff_gpu_vs_cholmod": float(np.linalg.norm(xs - xc) / np.linalg.norm(xc))}
+        except Exception as e:  # noqa: BLE001
+            out["cpu_baseline"] = {"value": None, "unit": "block-nnz/s", "cores": 1, "kind": "reference", "sample": "failed: %r" % (e,)}
+    if collective[0] != "allreduce" or len(collective) > 1:
+        out["config"]["collective"] = " / ".join(collective)
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -125,11 +125,8 @@ int spp_free_memory(spp_ctx *ctx)
 	ctx->dense.tinv.release();
 	ctx->dense.tinv_all.release();
 	ctx->dense.xtmp.release();
-	if(ctx->dense.gexec) {
-		(void)hipGraphExecDestroy(ctx->dense.gexec);
-		ctx->dense.gexec = nullptr;
-	}
-	ctx->dense.gseen = false;
+	ctx->dense.la_cnt.release();
+	ctx->dense.la_trace.release();
 	ctx->geom_partial.release();
 	ctx->dense.flags.release();
 	ctx->dense.epoch = 0;
@@ -158,6 +155,11 @@ void spp_destroy(spp_ctx *ctx)
 	if(ctx->dense.row) {
 		(void)hipStreamDestroy(ctx->dense.row);
 		(void)hipEventDestroy(ctx->dense.ev_row);
+	}
+	if(ctx->dense.chain) {
+		(void)hipStreamDestroy(ctx->dense.chain);
+		if(ctx->dense.ev_chain)
+			(void)hipEventDestroy(ctx->dense.ev_chain);
 	}
 	if(ctx->dense.h_chain_err)
 		(void)hipHostFree(ctx->dense.h_chain_err);
@@ -259,6 +261,7 @@ int spp_analyze(spp_ctx *ctx, int64_t nb, const int64_t *col_ptr, const int64_t 
 	// sizes of the NEW structure beside the plan of the OLD one (the next solve would copy the wrong extents).
 	// The old plan is dropped first in any case -- after a failed analyze the ctx is "not analyzed".
 	ctx->mode = -1;
+	VClock clk("spp_analyze");
 	Structure st;
 	st.nb = nb;
 	st.nnzb = col_ptr[nb];
@@ -289,8 +292,10 @@ int spp_analyze(spp_ctx *ctx, int64_t nb, const int64_t *col_ptr, const int64_t 
 	}
 	ctx->st = std::move(st);
 	Structure &st_ref = ctx->st;
+	clk.lap("structure copied + validated");
 	ctx->schur.release_all();
 	sparse_release(ctx);
+	clk.lap("old plans released");
 	int dp, dl;
 	int chosen = mode;
 	if(mode == SPP_MODE_AUTO) {

@@ -33,6 +33,7 @@ struct AssemblePlan {
 	Structure st;
 	int64_t n_ob = 0;
 	std::vector<int64_t> h_vlist_seq[2], h_vlist_wave[2]; // per vertex-dimension class (d0 / d1)
+	DevBuf<unsigned char> index_store; // the one allocation behind the index arrays below (UploadArena)
 	DevBuf<int32_t> ob_ptr;     // [n_ob+1]
 	DevBuf<int32_t> ob_edge;    // edge | reversed << 31
 	DevBuf<int64_t> ob_off;     // [n_ob] offset of the block in vals
@@ -74,6 +75,7 @@ void assemble_analyze(spp_ctx *ctx, int64_t nv, const int32_t *dim, int64_t ne, 
 		"edge group (d0, d1, rd) not instantiated: (6,3,2) (3,3,3) (6,6,6) (3,2,2)");
 	SPP_REQUIRE(ne < (int64_t(1) << 30), SPP_E_UNSUPPORTED, "too many edges for 31-bit edge indices");
 	assemble_release(ctx); // after a rejected call the ctx has NO assembly plan (spp_assemble_device then fails its state check)
+	VClock clk("assemble_analyze");
 	for(int64_t e = 0; e < ne; ++ e) {
 		SPP_REQUIRE(v0[e] >= 0 && v0[e] < nv && v1[e] >= 0 && v1[e] < nv && v0[e] != v1[e], SPP_E_BADARG, "bad edge");
 		SPP_REQUIRE(dim[v0[e]] == d0 && dim[v1[e]] == d1, SPP_E_BADARG, "vertex width does not match the edge group");
@@ -88,10 +90,37 @@ void assemble_analyze(spp_ctx *ctx, int64_t nv, const int32_t *dim, int64_t ne, 
 	std::vector<std::pair<int64_t, int64_t> > key(ne); // (col, row)
 	for(int64_t e = 0; e < ne; ++ e)
 		key[e] = std::make_pair(std::max(v0[e], v1[e]), std::min(v0[e], v1[e]));
+	// edges in (column, row, edge index) order: a counting sort by column (stable), then the rows inside each column --
+	// a handful per landmark column -- by insertion, longer runs by std::stable_sort (a comparison sort of all the
+	// edges was most of this function on a Venice-sized graph)
 	std::vector<int64_t> eorder(ne);
-	for(int64_t e = 0; e < ne; ++ e)
-		eorder[e] = e;
-	std::stable_sort(eorder.begin(), eorder.end(), [&](int64_t a, int64_t b) { return key[a] < key[b]; });
+	{
+		std::vector<int64_t> cstart(nv + 1, 0);
+		for(int64_t e = 0; e < ne; ++ e)
+			++ cstart[key[e].first + 1];
+		for(int64_t c = 0; c < nv; ++ c)
+			cstart[c + 1] += cstart[c];
+		std::vector<int64_t> fill(cstart.begin(), cstart.end() - 1);
+		for(int64_t e = 0; e < ne; ++ e)
+			eorder[fill[key[e].first] ++] = e;
+		for(int64_t c = 0; c < nv; ++ c) {
+			const int64_t b = cstart[c], n = cstart[c + 1] - b;
+			if(n <= 1)
+				continue;
+			if(n > 32) {
+				std::stable_sort(eorder.begin() + b, eorder.begin() + b + n, [&](int64_t x, int64_t y) { return key[x].second < key[y].second; });
+				continue;
+			}
+			for(int64_t i = 1; i < n; ++ i) { // stable insertion sort by row
+				const int64_t x = eorder[b + i], rx = key[x].second;
+				int64_t j = i;
+				for(; j > 0 && key[eorder[b + j - 1]].second > rx; -- j)
+					eorder[b + j] = eorder[b + j - 1];
+				eorder[b + j] = x;
+			}
+		}
+	}
+	clk.lap("edges sorted by block");
 	Structure &st = ap->st;
 	st.nb = nv;
 	st.dim.assign(dim, dim + nv);
@@ -104,6 +133,10 @@ void assemble_analyze(spp_ctx *ctx, int64_t nv, const int32_t *dim, int64_t ne, 
 	std::vector<int32_t> ob_ptr(1, 0), ob_edge;
 	std::vector<int64_t> ob_off, v_doff(nv);
 	ob_edge.reserve(ne);
+	ob_ptr.reserve(ne + 1);
+	ob_off.reserve(ne);
+	st.row_idx.reserve(ne + nv);
+	st.blk_off.reserve(ne + nv);
 	int64_t off = 0, q = 0;
 	for(int64_t c = 0; c < nv; ++ c) {
 		st.col_ptr[c] = (int64_t)st.row_idx.size();
@@ -129,6 +162,7 @@ void assemble_analyze(spp_ctx *ctx, int64_t nv, const int32_t *dim, int64_t ne, 
 	st.nnzb = st.col_ptr[nv];
 	st.nvals = off;
 	ap->n_ob = (int64_t)ob_off.size();
+	clk.lap("Lambda structure");
 	// ---- per-vertex contribution lists in edge order: (edge, side)
 	std::vector<int32_t> vl_ptr(nv + 1, 0), vl_entry(2 * ne);
 	for(int64_t e = 0; e < ne; ++ e) {
@@ -157,24 +191,28 @@ void assemble_analyze(spp_ctx *ctx, int64_t nv, const int32_t *dim, int64_t ne, 
 		else
 			lwave[cls].push_back((int32_t)v);
 	}
+	clk.lap("vertex lists");
 	hipStream_t s = ctx->stream;
-	ap->ob_ptr.upload(ob_ptr, s);
-	ap->ob_edge.upload(ob_edge, s);
-	ap->ob_off.upload(ob_off, s);
-	ap->vl_ptr.upload(vl_ptr, s);
-	ap->vl_entry.upload(vl_entry, s);
-	ap->v_doff.upload(v_doff, s);
+	UploadArena arena;
+	arena.add(ap->ob_ptr, ob_ptr);
+	arena.add(ap->ob_edge, ob_edge);
+	arena.add(ap->ob_off, ob_off);
+	arena.add(ap->vl_ptr, vl_ptr);
+	arena.add(ap->vl_entry, vl_entry);
+	arena.add(ap->v_doff, v_doff);
 	{
 		std::vector<int64_t> vb(st.base.begin(), st.base.end() - 1);
-		ap->v_base.upload(vb, s);
+		arena.add(ap->v_base, vb);
 	}
 	for(int cls = 0; cls < 2; ++ cls) {
 		ap->n_seq[cls] = (int64_t)lseq[cls].size();
 		ap->n_wave[cls] = (int64_t)lwave[cls].size();
-		ap->vlist_seq[cls].upload(lseq[cls], s);
-		ap->vlist_wave[cls].upload(lwave[cls], s);
+		arena.add(ap->vlist_seq[cls], lseq[cls]);
+		arena.add(ap->vlist_wave[cls], lwave[cls]);
 	}
+	arena.commit(ap->index_store, s);
 	SPP_HIP_CHECK(hipStreamSynchronize(s));
+	clk.lap("uploads");
 	// complete: install. The ctx now describes this Lambda (sizes for spp_get_info before spp_analyze is called);
 	// a solve plan analyzed for a DIFFERENT structure is dropped rather than left beside the new sizes
 	if(ctx->mode >= 0 && (ctx->st.nb != st.nb || ctx->st.n != st.n || ctx->st.nnzb != st.nnzb || ctx->st.nvals != st.nvals))

@@ -842,7 +842,7 @@ static void ensure_dense_work(spp_ctx *ctx, int64_t nblk)
 //   ncols  columns carried along (rows + 1 with a rhs column)
 // Does not synchronize; failures are recorded in ctx->dense.info (first failing pivot + 1).
 static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, int64_t n, int64_t rows, int64_t ncols,
-	int64_t nsteps, bool has_rhs, bool use_flags = false);
+	int64_t nsteps, bool has_rhs, bool use_flags = false, bool allow_fused = true);
 static bool flag_schedule_usable(spp_ctx *ctx);
 static void flag_signal(hipStream_t st, int *flag, int value);
 static void flag_wait(spp_ctx *ctx, hipStream_t st, const int *flag, int value, double timeout_ms = 500.0);
@@ -1022,60 +1022,21 @@ static void dense_factor_lookahead(spp_ctx *ctx, double *d_A, int64_t ld, int64_
 	}
 }
 
-// Optional (SPP_DENSE_GRAPH=1): the two-stream schedule of one factorization is captured into a hipGraph
-// the second time the same (buffer, shape) is factored and replayed afterwards -- the kernel arguments
-// are baked in, so the key is everything they depend on. Profiled solves (hipEvents between the
-// launches) always take the plain path.
+// Which schedule: the lookahead schedule (SPP_DENSE_LA=1), the two-stream schedule with device flags + the fused chain
+// kernel (default), or -- inside a stream capture, where monotonic counters and epochs passed as kernel arguments would
+// be replayed stale -- the two-stream schedule with events only and the three chain kernels as separate launches.
 void dense_factor_steps(spp_ctx *ctx, double *d_A, int64_t ld, int64_t n, int64_t rows, int64_t ncols,
 	int64_t nsteps, bool has_rhs)
 {
 	ensure_dense_work(ctx, nsteps);
-	static int use_graph = -1;
-	if(use_graph < 0) {
-		const char *e = getenv("SPP_DENSE_GRAPH");
-		use_graph = e ? atoi(e) : 0;
-	}
-	DenseWork &dw = ctx->dense;
-	if(la_usable(ctx, nsteps)) { // lookahead: persistent chain kernel + one bulk launch per step
+	hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+	const bool capturing = hipStreamIsCapturing(ctx->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
+	if(!capturing && la_usable(ctx, nsteps)) { // lookahead: persistent chain kernel + one bulk launch per step
 		dense_factor_lookahead(ctx, d_A, ld, n, rows, ncols, nsteps, has_rhs);
 		return;
 	}
-	if(nsteps >= 4 && flag_schedule_usable(ctx)) { // cross-stream hand-offs through device flags instead of events
-		dense_factor_steps_enqueue(ctx, d_A, ld, n, rows, ncols, nsteps, has_rhs, true);
-		return;
-	}
-	if(!use_graph || (ctx->flags & SPP_FLAG_PROFILE) || nsteps < 4) {
-		dense_factor_steps_enqueue(ctx, d_A, ld, n, rows, ncols, nsteps, has_rhs);
-		return;
-	}
-	const int64_t key[7] = {(int64_t)(uintptr_t)d_A, ld, n, rows, ncols, nsteps, has_rhs ? 1 : 0};
-	const bool same = !memcmp(key, dw.gkey, sizeof(key)) && dw.gstream == ctx->stream;
-	if(same && dw.gexec) {
-		SPP_HIP_CHECK(hipGraphLaunch(dw.gexec, ctx->stream));
-		return;
-	}
-	if(same && dw.gseen) { // second factorization of this buffer: every lazily initialized piece is warm
-		if(dw.gexec) {
-			(void)hipGraphExecDestroy(dw.gexec);
-			dw.gexec = nullptr;
-		}
-		hipGraph_t graph = nullptr;
-		SPP_HIP_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
-		dense_factor_steps_enqueue(ctx, d_A, ld, n, rows, ncols, nsteps, has_rhs);
-		SPP_HIP_CHECK(hipStreamEndCapture(ctx->stream, &graph));
-		SPP_HIP_CHECK(hipGraphInstantiate(&dw.gexec, graph, nullptr, nullptr, 0));
-		(void)hipGraphDestroy(graph);
-		SPP_HIP_CHECK(hipGraphLaunch(dw.gexec, ctx->stream));
-		return;
-	}
-	if(dw.gexec) {
-		(void)hipGraphExecDestroy(dw.gexec);
-		dw.gexec = nullptr;
-	}
-	memcpy(dw.gkey, key, sizeof(key));
-	dw.gstream = ctx->stream;
-	dw.gseen = true;
-	dense_factor_steps_enqueue(ctx, d_A, ld, n, rows, ncols, nsteps, has_rhs);
+	const bool flags = !capturing && nsteps >= 4 && flag_schedule_usable(ctx); // cross-stream hand-offs through device flags instead of events
+	dense_factor_steps_enqueue(ctx, d_A, ld, n, rows, ncols, nsteps, has_rhs, flags, !capturing);
 }
 
 static void flag_signal(hipStream_t st, int *flag, int value)
@@ -1139,7 +1100,7 @@ static bool flag_schedule_usable(spp_ctx *ctx)
 }
 
 static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, int64_t n, int64_t rows, int64_t ncols,
-	int64_t nsteps, bool has_rhs, bool use_flags)
+	int64_t nsteps, bool has_rhs, bool use_flags, bool allow_fused)
 {
 	hipStream_t s = ctx->stream, s2 = ctx->dense.aux;
 	hipEvent_t evA = ctx->dense.ev[0], evB = ctx->dense.ev[1];
@@ -1238,11 +1199,12 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 	bool row_pending = false; // the remainder of tile row k (stream ctx->dense.row) has to finish before panel k
 	// Fused chain kernel (update_potrf_kernel): the update of a row region from panel kp and the factorization of the
 	// region's first diagonal block (step kn) in one launch; the panel solve of step kn follows as its own launch.
-	static int fused = -1;
-	if(fused < 0) {
+	static int fused_env = -1;
+	if(fused_env < 0) {
 		const char *e = getenv("SPP_FUSED"); // 0: tile row / update, potrf_diag and panel solve as three launches (round 1)
-		fused = e ? atoi(e) : 1;
+		fused_env = e ? atoi(e) : 1;
 	}
+	const int fused = allow_fused ? fused_env : 0; // (its sub-tile counters are monotonic: not inside a stream capture)
 	if(fused) {
 		static bool fattr = false;
 		if(!fattr) {
@@ -1527,7 +1489,7 @@ void dense_chain_check(spp_ctx *ctx)
 	}
 }
 
-int dense_info_fetch(spp_ctx *ctx)
+int dense_info_fetch(spp_ctx *ctx, bool *dag_aborted)
 {
 	int h_info[4] = {0, 0, 0, 0};
 	SPP_HIP_CHECK(hipMemcpyAsync(h_info, ctx->dense.info.p, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -1535,6 +1497,10 @@ int dense_info_fetch(spp_ctx *ctx)
 	if(h_info[3]) { // a front of the dependency-driven sparse launches timed out waiting for a child / its parent
 		SPP_HIP_CHECK(hipMemset(ctx->dense.info.p + 3, 0, sizeof(int)));
 		sparse_dag_disable(ctx);
+		if(dag_aborted) { // the caller repeats the solve level by level
+			*dag_aborted = true;
+			return 0;
+		}
 		throw Error(SPP_E_HIP, "sparse factorization: a front timed out waiting for another front's flag; "
 			"the following calls launch level by level");
 	}

@@ -7,6 +7,11 @@
 #include <string>
 #include <vector>
 #include <stdexcept>
+#include <algorithm>
+#include <string.h>
+#include <chrono>
+#include <stdio.h>
+#include <stdlib.h>
 #include "../../include/spp_hip.h"
 
 namespace spp {
@@ -23,6 +28,22 @@ struct Error : std::runtime_error {
 	throw spp::Error(SPP_E_HIP, std::string(#expr " failed: ") + hipGetErrorString(e_)); } while(0)
 #define SPP_REQUIRE(cond, code, msg) do { if(!(cond)) throw spp::Error((code), (msg)); } while(0)
 
+// wall clock of the host-side phases of an analysis, printed lap by lap when SPP_VERBOSE is set
+struct VClock {
+	const char *who;
+	std::chrono::steady_clock::time_point t;
+	bool on;
+	explicit VClock(const char *w) : who(w), t(std::chrono::steady_clock::now()), on(getenv("SPP_VERBOSE") != nullptr) {}
+	void lap(const char *what)
+	{
+		if(!on)
+			return;
+		const std::chrono::steady_clock::time_point n = std::chrono::steady_clock::now();
+		fprintf(stderr, "[spp] %s: %-34s %8.2f ms\n", who, what, std::chrono::duration<double>(n - t).count() * 1e3);
+		t = n;
+	}
+};
+
 // ------------------------------------------------------------------------------------------------
 // device buffer (owned, grows geometrically like the reference's workspaces,
 // LinearSolver_UberBlock.h:332-348)
@@ -31,14 +52,29 @@ template <class T>
 struct DevBuf {
 	T *p = nullptr;
 	size_t cap = 0; // elements
+	bool owned = true; // false: a view into an UploadArena's single allocation
 	DevBuf() {}
 	DevBuf(const DevBuf&) = delete;
 	DevBuf &operator=(const DevBuf&) = delete;
 	~DevBuf() { release(); }
-	void release() { if(p) { (void)hipFree(p); p = nullptr; cap = 0; } }
+	void release()
+	{
+		if(p && owned)
+			(void)hipFree(p);
+		p = nullptr;
+		cap = 0;
+		owned = true;
+	}
+	void view(T *ptr, size_t n)
+	{
+		release();
+		p = ptr;
+		cap = n;
+		owned = false;
+	}
 	void reserve(size_t n)
 	{
-		if(n <= cap)
+		if(n <= cap && owned)
 			return;
 		release();
 		size_t want = n;
@@ -54,6 +90,38 @@ struct DevBuf {
 		reserve(h.size() ? h.size() : 1);
 		if(!h.empty())
 			SPP_HIP_CHECK(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
+	}
+};
+
+// The index arrays of a plan -- a few dozen of them, kilobytes to megabytes each -- in ONE device allocation filled by ONE
+// copy: a hipMalloc + a pageable-memory hipMemcpyAsync per array was most of the analysis time of a pose graph
+// (26 arrays: 10-18 ms of a 14 ms sparse_analyze). add() stages a vector, commit() uploads everything and turns the
+// DevBufs into views of the allocation `store` owns; the host image must live until the stream has been synchronized.
+struct UploadArena {
+	std::vector<unsigned char> host;
+	struct Item { void **pp; size_t *pcap; bool *powned; size_t off, n; };
+	std::vector<Item> items;
+	template <class T>
+	void add(DevBuf<T> &b, const std::vector<T> &v)
+	{
+		b.release();
+		const size_t off = (host.size() + 255) & ~(size_t)255, bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+		host.resize(off + bytes);
+		if(!v.empty())
+			memcpy(host.data() + off, v.data(), v.size() * sizeof(T));
+		Item it = {(void**)&b.p, &b.cap, &b.owned, off, std::max<size_t>(v.size(), 1)};
+		items.push_back(it);
+	}
+	void commit(DevBuf<unsigned char> &store, hipStream_t s)
+	{
+		store.release();
+		store.reserve(std::max<size_t>(host.size(), 256));
+		SPP_HIP_CHECK(hipMemcpyAsync(store.p, host.data(), host.size(), hipMemcpyHostToDevice, s));
+		for(size_t i = 0; i < items.size(); ++ i) {
+			*items[i].pp = store.p + items[i].off;
+			*items[i].pcap = items[i].n;
+			*items[i].powned = false;
+		}
 	}
 };
 
@@ -146,11 +214,6 @@ struct DenseWork {
 	DevBuf<int> flags;             // per block row: epoch of the solve that last published x_b (chain kernel)
 	int epoch = 0;
 	int *h_chain_err = nullptr;
-	// optional hipGraph of one factorization (SPP_DENSE_GRAPH): key = buffer + shape, see dense_factor_steps
-	hipGraphExec_t gexec = nullptr;
-	int64_t gkey[7] = {0, 0, 0, 0, 0, 0, 0};
-	hipStream_t gstream = nullptr;
-	bool gseen = false;    // pinned: timeout flag of the chain kernel, valid after a stream sync
 	hipStream_t aux = nullptr;     // lookahead stream: potrf_diag + trsm of the next panel
 	hipEvent_t ev[2] = {nullptr, nullptr};
 	hipStream_t row = nullptr;     // third stream: the part of tile row k+1 that only the NEXT panel solve needs
@@ -266,7 +329,7 @@ void schur_pack(spp_ctx *ctx, double *S, double *packed, bool pack);
 constexpr int DENSE_NB = 128;
 int dense_potrf_upper(spp_ctx *ctx, double *d_A, int64_t n, int64_t ld, bool keep_inverses);
 void dense_potrf_upper_enqueue(spp_ctx *ctx, double *d_A, int64_t n, int64_t ld);
-int dense_info_fetch(spp_ctx *ctx);
+int dense_info_fetch(spp_ctx *ctx, bool *dag_aborted = nullptr); // dag_aborted given: a timed-out sparse launch is reported there instead of thrown
 void dense_potrs_upper(spp_ctx *ctx, const double *d_R, int64_t n, int64_t ld, double *d_b);
 void dense_factor_steps(spp_ctx *ctx, double *d_A, int64_t ld, int64_t n, int64_t rows, int64_t ncols,
 	int64_t nsteps, bool has_rhs);

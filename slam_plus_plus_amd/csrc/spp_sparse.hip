@@ -28,6 +28,8 @@
 #include "spp_tiles.h"
 #include "spp_dense_dev.h"
 #include <algorithm>
+#include <thread>
+#include <exception>
 #include <numeric>
 #include <stdio.h>
 #include <stdlib.h>
@@ -36,18 +38,7 @@
 namespace spp {
 
 struct SparsePlan {
-	// hipGraph of one factor + solve (kernel arguments baked in: valid for one (values, rhs, stream) triple of THIS
-	// plan; captured on the second solve with the same triple, when every lazily created resource exists)
-	hipGraphExec_t gexec = nullptr;
-	const double *gvals = nullptr;
-	double *grhs = nullptr;
-	hipStream_t gstream = nullptr;
-	bool gseen = false;
-	~SparsePlan()
-	{
-		if(gexec)
-			(void)hipGraphExecDestroy(gexec);
-	}
+	DevBuf<unsigned char> index_store;         // the one allocation behind the index arrays below (UploadArena)
 	int64_t nb = 0, n = 0;
 	int64_t n_snodes = 0, n_levels = 0;
 	int64_t front_doubles = 0, vbuf_doubles = 0;
@@ -223,37 +214,45 @@ void sparse_analyze(spp_ctx *ctx, const Structure &st)
 	// ---- 1. + 2. fill-reducing order, postorder of its elimination tree, row structure of every row
 	// of R (= column structure of L, children merged upward): rstruct[j] = sorted block columns c > j
 	// with R(j, c) != 0
-	std::vector<int64_t> inv(nb), order(nb);
-	std::vector<std::vector<int32_t> > up, rstruct;
-	std::vector<int32_t> parent, post;
-	double sym_flops = 0; // sum_j (row count)^2, block level
-	int64_t sym_height = 0; // longest root-to-leaf path of the elimination tree, in block columns
-	auto symbolic = [&](const std::vector<int64_t> &order0) {
+	VClock clk("sparse_analyze");
+	struct Symbolic {
+		std::vector<int64_t> order;
+		std::vector<std::vector<int32_t> > rstruct;
+		std::vector<int32_t> parent;
+		double flops = 0;   // sum_j (row count)^2, block level
+		int64_t height = 0; // longest root-to-leaf path of the elimination tree, in block columns
+	};
+	auto symbolic = [&st, nb](const std::vector<int64_t> &order0, Symbolic &y) {
+		std::vector<int64_t> inv(nb);
+		std::vector<std::vector<int32_t> > up;
+		std::vector<int32_t> post;
 		for(int64_t k = 0; k < nb; ++ k)
 			inv[order0[k]] = k;
 		permuted_pattern(st, inv, up);
-		etree_of(nb, up, parent);
-		postorder(parent, post);
+		etree_of(nb, up, y.parent);
+		postorder(y.parent, post);
+		y.order.resize(nb);
 		for(int64_t k = 0; k < nb; ++ k)
-			order[k] = order0[post[k]];
+			y.order[k] = order0[post[k]];
 		for(int64_t k = 0; k < nb; ++ k)
-			inv[order[k]] = k;
+			inv[y.order[k]] = k;
 		permuted_pattern(st, inv, up);
-		etree_of(nb, up, parent);
+		etree_of(nb, up, y.parent);
+		std::vector<std::vector<int32_t> > &rstruct = y.rstruct;
 		rstruct.assign(nb, std::vector<int32_t>());
 		// entries of A in row j right of the diagonal: from the permuted upper pattern, (a, b) a < b
 		for(int64_t b = 0; b < nb; ++ b)
 			for(size_t q = 0; q < up[b].size(); ++ q)
 				rstruct[up[b][q]].push_back((int32_t)b);
-		sym_flops = 0;
+		y.flops = 0;
 		std::vector<int32_t> depth(nb, 1);
 		for(int64_t j = 0; j < nb; ++ j) {
 			std::vector<int32_t> &rs = rstruct[j];
 			std::sort(rs.begin(), rs.end());
 			rs.erase(std::unique(rs.begin(), rs.end()), rs.end());
-			sym_flops += (double)(rs.size() + 1) * (double)(rs.size() + 1);
+			y.flops += (double)(rs.size() + 1) * (double)(rs.size() + 1);
 			// push to the parent: struct[parent] U= struct[j] \ {parent}
-			const int32_t p = parent[j];
+			const int32_t p = y.parent[j];
 			SPP_REQUIRE(p < 0 || (!rs.empty() && rs[0] == p), SPP_E_HIP, "internal: etree/structure mismatch");
 			if(p >= 0) {
 				// ps is not sorted yet (raw A entries): append, it is sorted/uniqued when p is visited
@@ -262,35 +261,67 @@ void sparse_analyze(spp_ctx *ctx, const Structure &st)
 				depth[p] = std::max(depth[p], depth[j] + 1);
 			}
 		}
-		sym_height = 0;
+		y.height = 0;
 		for(int64_t j = 0; j < nb; ++ j)
-			sym_height = std::max<int64_t>(sym_height, depth[j]);
+			y.height = std::max<int64_t>(y.height, depth[j]);
 	};
+	Symbolic chosen_sym;
 	{
 		// Minimum degree gives the least fill; on chain-like graphs its elimination tree is one long
 		// chain, though, and the level-scheduled kernels then run one small front after the other.
 		// Nested dissection is taken instead when it cuts the tree height by more than 4x at no more
 		// than 3x the block-level flops, or when it is simply better on both counts.
-		// SPP_ORDERING = amd | nd forces one of them.
-		std::vector<int64_t> amd, nd;
-		min_degree_order(nb, st.col_ptr.data(), st.row_idx.data(), amd);
-		symbolic(amd);
+		// SPP_ORDERING = amd | nd forces one of them. The two candidates (ordering + symbolic factorization each) are
+		// independent: they run side by side on two host threads.
 		const char *force = getenv("SPP_ORDERING");
 		const bool want_nd = force ? !strcmp(force, "nd") : (nb >= 256);
+		Symbolic y_amd, y_nd;
+		std::exception_ptr err_nd;
+		std::thread t_nd;
+		if(want_nd)
+			t_nd = std::thread([&]() {
+				try {
+					std::vector<int64_t> nd;
+					nested_dissection_order(nb, st.col_ptr.data(), st.row_idx.data(), nd);
+					symbolic(nd, y_nd);
+				} catch(...) {
+					err_nd = std::current_exception();
+				}
+			});
+		try {
+			std::vector<int64_t> amd;
+			min_degree_order(nb, st.col_ptr.data(), st.row_idx.data(), amd);
+			symbolic(amd, y_amd);
+		} catch(...) {
+			if(t_nd.joinable())
+				t_nd.join();
+			throw;
+		}
+		if(t_nd.joinable())
+			t_nd.join();
+		if(err_nd)
+			std::rethrow_exception(err_nd);
+		bool take = false;
 		if(want_nd) {
-			const double f_amd = sym_flops;
-			const int64_t h_amd = sym_height;
-			nested_dissection_order(nb, st.col_ptr.data(), st.row_idx.data(), nd);
-			symbolic(nd);
-			const bool take = force ? true : ((4 * sym_height < h_amd && sym_flops <= 3.0 * f_amd) ||
-				(sym_height < h_amd && sym_flops <= 1.02 * f_amd));
+			take = force ? true : ((4 * y_nd.height < y_amd.height && y_nd.flops <= 3.0 * y_amd.flops) ||
+				(y_nd.height < y_amd.height && y_nd.flops <= 1.02 * y_amd.flops));
 			if(getenv("SPP_VERBOSE"))
 				fprintf(stderr, "[spp] ordering: amd height %lld flops %.3g | nd height %lld flops %.3g -> %s\n",
-					(long long)h_amd, f_amd, (long long)sym_height, sym_flops, take ? "nd" : "amd");
-			if(!take)
-				symbolic(amd);
+					(long long)y_amd.height, y_amd.flops, (long long)y_nd.height, y_nd.flops, take ? "nd" : "amd");
 		}
+		chosen_sym = std::move(take ? y_nd : y_amd);
 	}
+	std::vector<int64_t> &order = chosen_sym.order;
+	std::vector<std::vector<int32_t> > &rstruct = chosen_sym.rstruct;
+	std::vector<int32_t> &parent = chosen_sym.parent;
+	const double sym_flops = chosen_sym.flops;
+	(void)sym_flops;
+	const int64_t sym_height = chosen_sym.height;
+	(void)sym_height;
+	std::vector<int64_t> inv(nb);
+	for(int64_t k = 0; k < nb; ++ k)
+		inv[order[k]] = k;
+	clk.lap("orderings + symbolic factorization");
 	ctx->order = order;
 
 	// ---- 3. fundamental supernodes + relaxed amalgamation of the last child
@@ -387,6 +418,7 @@ void sparse_analyze(spp_ctx *ctx, const Structure &st)
 	const int64_t ns = (int64_t)sn_first.size();
 	sp->n_snodes = ns;
 
+	clk.lap("supernodes + amalgamation");
 	// ---- 4. per supernode: block row structure (own columns, then the union of the rows beyond)
 	std::vector<int32_t> pdim(nb);
 	std::vector<int64_t> pbase(nb + 1, 0);
@@ -437,6 +469,7 @@ void sparse_analyze(spp_ctx *ctx, const Structure &st)
 			sp->h_level_fronts[fill[level[s]] ++] = (int32_t)s;
 	}
 
+	clk.lap("front structures + levels");
 	// ---- 6. flat arrays
 	std::vector<int32_t> front_h(ns), front_w(ns), front_ld(ns), front_pad(ns), front_cls(ns), rows_ptr(ns + 1, 0), rows;
 	std::vector<int64_t> front_off(ns), front_voff(ns);
@@ -500,11 +533,12 @@ void sparse_analyze(spp_ctx *ctx, const Structure &st)
 			sp->h_level_fronts[fill[level[q] * NCLS + front_cls[q]] ++] = (int32_t)q;
 	}
 	{
-		int64_t max_steps = 1;
+		int64_t max_steps = 0;
 		for(int64_t q = 0; q < ns; ++ q)
 			if(front_cls[q] == 4)
 				max_steps = std::max<int64_t>(max_steps, (front_w[q] + front_pad[q]) / DENSE_NB);
-		dense_reserve(ctx, max_steps);
+		if(max_steps > 0) // (a tree without big fronts never calls the dense factor: no streams, no block inverses)
+			dense_reserve(ctx, max_steps);
 	}
 	// dependency-driven part: every level below the first one that holds a big front the launch cannot take; with teams
 	// (SPP_SPARSE_TEAMS, default on) it takes the big fronts as well -- G consecutive workgroups each -- and covers the
@@ -516,6 +550,14 @@ void sparse_analyze(spp_ctx *ctx, const Structure &st)
 		bool teams = true;
 		if(const char *e = getenv("SPP_SPARSE_TEAMS"))
 			teams = atoi(e) != 0;
+		// a team's counter barrier needs ALL of its members resident at once (one 1024-thread workgroup with ~137 KB of LDS
+		// per CU): never more members than half the CUs of this device (a partitioned or CU-masked device), and no teams
+		// at all on one that cannot hold a team of two beside the rest of the launch
+		hipDeviceProp_t prop;
+		SPP_HIP_CHECK(hipGetDeviceProperties(&prop, ctx->device));
+		const int team_cap = prop.multiProcessorCount / 2;
+		if(team_cap < 2)
+			teams = false;
 		int32_t limit = (int32_t)sp->n_levels;
 		if(!teams)
 			for(int64_t q = 0; q < ns; ++ q)
@@ -536,6 +578,7 @@ void sparse_analyze(spp_ctx *ctx, const Structure &st)
 		int team_max = 40, team_cols = 16; // measured on sphere2500: 12 / 64 -> 1.55 ms, 24 / 32 -> 1.34, 32 / 16 -> 1.27, 48 / 16 -> 1.26, 64 / 8 -> 1.36
 		if(const char *e = getenv("SPP_SPARSE_TEAM_MAX"))
 			team_max = std::max(1, std::min(64, atoi(e)));
+		team_max = std::max(2, std::min(team_max, team_cap));
 		if(const char *e = getenv("SPP_SPARSE_TEAM_COLS")) // columns of the padded front per member
 			team_cols = std::max(8, std::min(256, atoi(e)));
 		for(size_t i = 0; i < fronts_in.size(); ++ i) {
@@ -692,32 +735,34 @@ void sparse_analyze(spp_ctx *ctx, const Structure &st)
 			}
 	}
 	hipStream_t s = ctx->stream;
-	sp->level_fronts.upload(sp->h_level_fronts, s);
-	sp->front_off.upload(front_off, s);
-	sp->front_h.upload(front_h, s);
-	sp->front_w.upload(front_w, s);
-	sp->front_ld.upload(front_ld, s);
-	sp->front_pad.upload(front_pad, s);
-	sp->front_voff.upload(front_voff, s);
-	sp->asm_ptr.upload(asm_ptr, s);
-	sp->asm_src.upload(asm_src, s);
-	sp->asm_dst.upload(asm_dst, s);
-	sp->asm_shape.upload(asm_shape, s);
-	sp->child_ptr.upload(child_ptr, s);
-	sp->child_list.upload(child_list, s);
-	sp->rel_ptr.upload(rel_ptr, s);
-	sp->rel.upload(rel, s);
-	sp->rows_ptr.upload(rows_ptr, s);
-	sp->rows.upload(rows, s);
-	sp->perm_scalar.upload(perm_scalar, s);
-	sp->front_cls.upload(front_cls, s);
-	sp->front_parent.upload(sn_parent, s);
-	sp->front_level.upload(level, s);
-	sp->dag_list.upload(dag_list, s);
-	sp->dag_list_bwd.upload(dag_list_bwd, s);
-	sp->dag_rank.upload(dag_rank, s);
-	sp->front_team.upload(front_team, s);
-	sp->front_tinv.upload(front_tinv, s);
+	UploadArena arena;
+	arena.add(sp->level_fronts, sp->h_level_fronts);
+	arena.add(sp->front_off, front_off);
+	arena.add(sp->front_h, front_h);
+	arena.add(sp->front_w, front_w);
+	arena.add(sp->front_ld, front_ld);
+	arena.add(sp->front_pad, front_pad);
+	arena.add(sp->front_voff, front_voff);
+	arena.add(sp->asm_ptr, asm_ptr);
+	arena.add(sp->asm_src, asm_src);
+	arena.add(sp->asm_dst, asm_dst);
+	arena.add(sp->asm_shape, asm_shape);
+	arena.add(sp->child_ptr, child_ptr);
+	arena.add(sp->child_list, child_list);
+	arena.add(sp->rel_ptr, rel_ptr);
+	arena.add(sp->rel, rel);
+	arena.add(sp->rows_ptr, rows_ptr);
+	arena.add(sp->rows, rows);
+	arena.add(sp->perm_scalar, perm_scalar);
+	arena.add(sp->front_cls, front_cls);
+	arena.add(sp->front_parent, sn_parent);
+	arena.add(sp->front_level, level);
+	arena.add(sp->dag_list, dag_list);
+	arena.add(sp->dag_list_bwd, dag_list_bwd);
+	arena.add(sp->dag_rank, dag_rank);
+	arena.add(sp->front_team, front_team);
+	arena.add(sp->front_tinv, front_tinv);
+	arena.commit(sp->index_store, s);
 	sp->team_tinv.reserve((size_t)std::max<int64_t>(tinv_doubles, 1));
 	sp->team_bar.reserve((size_t)std::max<int64_t>(ns, 1));
 	SPP_HIP_CHECK(hipMemsetAsync(sp->team_bar.p, 0, (size_t)std::max<int64_t>(ns, 1) * sizeof(int), s));
@@ -728,7 +773,9 @@ void sparse_analyze(spp_ctx *ctx, const Structure &st)
 	sp->fronts.reserve((size_t)std::max<int64_t>(foff, 2));
 	sp->vbuf.reserve((size_t)std::max<int64_t>(voff, 1));
 	sp->xperm.reserve((size_t)st.n);
+	clk.lap("maps built, uploads enqueued");
 	SPP_HIP_CHECK(hipStreamSynchronize(s));
+	clk.lap("uploads done");
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -1528,10 +1575,14 @@ __global__ void gather_perm_kernel(int64_t n, const int32_t *__restrict__ perm, 
 		dst[i] = src[perm[i]];
 }
 
+// `abort` (nullable): the word a timed-out flag wait of the dependency-driven launches sets -- the right-hand side is then
+// left as it came in, and the host repeats the solve level by level from the intact inputs
 __global__ void scatter_perm_kernel(int64_t n, const int32_t *__restrict__ perm, const double *__restrict__ src,
-	double *__restrict__ dst)
+	double *__restrict__ dst, const int *__restrict__ abort)
 {
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if(abort && *abort)
+		return;
 	if(i < n)
 		dst[perm[i]] = src[i];
 }
@@ -1572,55 +1623,24 @@ static void launch_front_lds(spp_ctx *ctx, SparsePlan *sp, int32_t b, int32_t e,
 
 static void sparse_enqueue(spp_ctx *ctx, const double *d_vals, double *d_rhs);
 
-// Optional (SPP_SPARSE_GRAPH=1): factor + solves as ONE hipGraph launch from the third solve with the same buffers
-// on -- the pose-graph sized systems are a sequence of 60..200 short kernels, several of them shorter than a launch.
-// Measured: 1 - 2.5 % per solve (manhattan3500 0.927 -> 0.904 ms, sphere2500 2.745 -> 2.723 ms), against a one-time
-// capture + instantiation of ~80 ms per (values, rhs) pair: off by default. Profiled solves always take the plain
-// path (their hipEvents sit between the launches).
+// (A hipGraph replay of the whole solve was measured at 1 - 2.5 % per solve in round 1 and cannot carry the dependency-
+// driven launches -- epochs and counters are kernel arguments --: removed.)
 int sparse_factor_solve(spp_ctx *ctx, const double *d_vals, double *d_rhs)
 {
 	SparsePlan *sp = ctx->sparse;
 	SPP_REQUIRE(sp, SPP_E_STATE, "sparse plan missing");
-	static int use_graph = -1;
-	if(use_graph < 0) {
-		const char *e = getenv("SPP_SPARSE_GRAPH");
-		use_graph = e ? atoi(e) : 0;
-	}
-	const bool same = sp->gvals == d_vals && sp->grhs == d_rhs && sp->gstream == ctx->stream;
-	if(!use_graph || (ctx->flags & SPP_FLAG_PROFILE))
-		sparse_enqueue(ctx, d_vals, d_rhs);
-	else if(same && sp->gexec)
-		SPP_HIP_CHECK(hipGraphLaunch(sp->gexec, ctx->stream));
-	else if(same && sp->gseen) {
-		hipGraph_t graph = nullptr;
-		SPP_HIP_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
-		try {
-			sparse_enqueue(ctx, d_vals, d_rhs);
-		} catch(...) {
-			(void)hipStreamEndCapture(ctx->stream, &graph);
-			if(graph)
-				(void)hipGraphDestroy(graph);
-			throw;
-		}
-		SPP_HIP_CHECK(hipStreamEndCapture(ctx->stream, &graph));
-		SPP_HIP_CHECK(hipGraphInstantiate(&sp->gexec, graph, nullptr, nullptr, 0));
-		(void)hipGraphDestroy(graph);
-		SPP_HIP_CHECK(hipGraphLaunch(sp->gexec, ctx->stream));
-	} else {
-		if(sp->gexec) {
-			(void)hipGraphExecDestroy(sp->gexec);
-			sp->gexec = nullptr;
-		}
-		sp->gvals = d_vals;
-		sp->grhs = d_rhs;
-		sp->gstream = ctx->stream;
-		sp->gseen = true;
-		sparse_enqueue(ctx, d_vals, d_rhs);
-	}
+	sparse_enqueue(ctx, d_vals, d_rhs);
 	// the status is fetched after the solves (no host round trip between factorization and solves)
-	if(dense_info_fetch(ctx))
-		return SPP_NOT_POSDEF;
-	return SPP_OK;
+	bool dag_aborted = false;
+	int info = dense_info_fetch(ctx, &dag_aborted);
+	if(dag_aborted) {
+		// a front of the dependency-driven launches timed out waiting for another front's flag (a device that does not
+		// keep the launch's workgroups resident): the right-hand side was left untouched, the plan now launches level by
+		// level -- the same solve again, from the intact inputs
+		sparse_enqueue(ctx, d_vals, d_rhs);
+		info = dense_info_fetch(ctx);
+	}
+	return info ? SPP_NOT_POSDEF : SPP_OK;
 }
 
 static void sparse_enqueue(spp_ctx *ctx, const double *d_vals, double *d_rhs)
@@ -1636,9 +1656,6 @@ static void sparse_enqueue(spp_ctx *ctx, const double *d_vals, double *d_rhs)
 	if(use_dag < 0) {
 		const char *e = getenv("SPP_SPARSE_DAG"); // 0: one launch per level and size class (round 1 / 2 schedule)
 		use_dag = e ? atoi(e) : 1;
-		if(const char *g = getenv("SPP_SPARSE_GRAPH")) // (a captured graph would replay a stale epoch)
-			if(atoi(g))
-				use_dag = 0;
 	}
 	const bool dag = use_dag && sp->dag_ok && sp->dag_n > 0;
 	const int32_t first_level = dag ? sp->dag_level_limit : 0;
@@ -1649,7 +1666,12 @@ static void sparse_enqueue(spp_ctx *ctx, const double *d_vals, double *d_rhs)
 	da.done = sp->dag_done.p;
 	da.level_limit = sp->dag_level_limit;
 	da.abort = ctx->dense.info.p + 3;
-	da.timeout_ticks = (long long)(500.0 * 1e5); // 500 ms of the 100 MHz wall clock
+	static long long dag_timeout = -1;
+	if(dag_timeout < 0) {
+		const char *e = getenv("SPP_DAG_TIMEOUT_TICKS"); // debugging / tests: a tiny value forces the timeout fallback
+		dag_timeout = e ? atoll(e) : (long long)(500.0 * 1e5); // 500 ms of the 100 MHz wall clock
+	}
+	da.timeout_ticks = dag_timeout;
 	da.epoch = 0;
 	da.level_first = 0;
 	da.list = nullptr;
@@ -1666,6 +1688,14 @@ static void sparse_enqueue(spp_ctx *ctx, const double *d_vals, double *d_rhs)
 			SPP_HIP_CHECK(hipFuncSetAttribute((const void*)front_dag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
 				(int)(std::max<size_t>(std::max<size_t>((size_t)17 * MID_FRONT_MAX + MID_FRONT_MAX, (size_t)128 * 129 + 128) + 2 * 16 * PT + 8, TEAM_LDS_DOUBLES) * sizeof(double))));
 			attr = true;
+		}
+		if(sp->dag_solves >= (1 << 18) || sp->dag_epoch >= (1 << 30)) {
+			// the teams' barrier counters and the fronts' epochs are monotonic 32-bit words (solve_index * G * barriers per
+			// solve stays below 2^31 for 2^18 solves of the largest team): start over long before they wrap
+			SPP_HIP_CHECK(hipMemsetAsync(sp->team_bar.p, 0, sp->team_bar.cap * sizeof(int), s));
+			SPP_HIP_CHECK(hipMemsetAsync(sp->dag_done.p, 0, sp->dag_done.cap * sizeof(int), s));
+			sp->dag_solves = 0;
+			sp->dag_epoch = 0;
 		}
 		da.epoch = ++ sp->dag_epoch;
 		da.solve_index = sp->dag_solves ++;
@@ -1780,7 +1810,8 @@ static void sparse_enqueue(spp_ctx *ctx, const double *d_vals, double *d_rhs)
 		da.list = sp->dag_list_bwd.p;
 		hipLaunchKernelGGL(front_bwd_dag_kernel, dim3((unsigned)sp->dag_n_bwd), dim3(1024), 0, s, da, make_front_args(ctx, sp, d_vals));
 	}
-	hipLaunchKernelGGL(scatter_perm_kernel, dim3(gn), dim3(256), 0, s, sp->n, sp->perm_scalar.p, sp->xperm.p, d_rhs);
+	hipLaunchKernelGGL(scatter_perm_kernel, dim3(gn), dim3(256), 0, s, sp->n, sp->perm_scalar.p, sp->xperm.p, d_rhs,
+		dag ? ctx->dense.info.p + 3 : nullptr);
 	phase_end(ctx, SPP_PHASE_TRISOLVE);
 	SPP_HIP_CHECK(hipGetLastError());
 }

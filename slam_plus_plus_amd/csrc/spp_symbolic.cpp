@@ -205,22 +205,9 @@ struct SchurPlanHost {
 	Structure s_st;
 };
 
-struct PlanClock {
-	std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
-	bool on = getenv("SPP_VERBOSE") != nullptr;
-	void lap(const char *what)
-	{
-		if(!on)
-			return;
-		const auto n = std::chrono::steady_clock::now();
-		fprintf(stderr, "[spp] schur plan: %-28s %7.2f ms\n", what, std::chrono::duration<double>(n - t).count() * 1e3);
-		t = n;
-	}
-};
-
 static void schur_plan_host(const Structure &st, int shard_rank, int shard_world, bool sparse_S, bool mis, SchurPlanHost &h)
 {
-	PlanClock clk;
+	VClock clk("schur plan");
 	int dp, dl;
 	std::vector<uint8_t> &is_lm = h.is_lm;
 	if(mis) {
@@ -733,6 +720,7 @@ void build_schur_plan(spp_ctx *ctx, bool sparse_S, bool mis)
 	hipStream_t s = ctx->stream;
 	SchurPlanHost h;
 	schur_plan_host(st, ctx->shard_rank, ctx->shard_world, sparse_S, mis, h);
+	VClock clk("schur plan (device)");
 	const int dp = h.dp, dl = h.dl;
 	const int64_t nc = h.nc, nl = h.nl, no = h.no;
 	sp.dp = dp;
@@ -783,6 +771,7 @@ void build_schur_plan(spp_ctx *ctx, bool sparse_S, bool mis)
 	}
 	sp.multi_blk.upload(h.multi_blk, s);
 	sp.multi_ptr.upload(h.multi_ptr, s);
+	clk.lap("uploads enqueued");
 	sp.cinv.reserve((size_t)std::max<int64_t>(1, nl) * dl * dl);
 	sp.W.reserve((size_t)std::max<int64_t>(1, no) * dp * dl);
 	if(sp.factored)
@@ -791,10 +780,13 @@ void build_schur_plan(spp_ctx *ctx, bool sparse_S, bool mis)
 		sp.Up.reserve((size_t)std::max<int64_t>(1, no) * dp * dl);
 	sp.xw.reserve((size_t)std::max<int64_t>(1, no) * dp);
 	sp.partial.reserve((size_t)std::max<int32_t>(1, h.n_slots) * dp * dp);
+	clk.lap("workspaces allocated");
 	SPP_HIP_CHECK(hipStreamSynchronize(s)); // host vectors die here
+	clk.lap("uploads done");
 
 	if(!sparse_S)
 		dense_reserve(ctx, (sp.n_red + DENSE_NB - 1) / DENSE_NB);
+	clk.lap("dense workspaces");
 
 	// ---- accounting (SURVEY 8d "Schur" + "Dense reduced solve")
 	const double n = (double)sp.n_red;

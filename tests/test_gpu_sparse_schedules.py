@@ -56,3 +56,12 @@ def test_fallback_schedules_match_the_dependency_driven_one(tmp_path):
     assert np.linalg.norm(x_noteam - x_dag) / n < 1e-6
     assert np.linalg.norm(x_levels - x_dag) / n < 1e-6
     assert np.array_equal(x_split, x_dag)  # the same fronts in the same order: only the launch boundaries differ
+
+
+def test_timed_out_dag_launch_is_repeated_level_by_level(tmp_path):
+    """SPP_DAG_TIMEOUT_TICKS=1 makes the first flag wait of the dependency-driven launch time out: the solve must not
+    fail -- the right-hand side is left untouched by the aborted launch, the library repeats the solve level by level
+    (and stays there) -- and must give exactly the level-by-level schedule's solution."""
+    x_levels = _run(tmp_path, "levels2", {"SPP_SPARSE_DAG": "0"})
+    x_abort = _run(tmp_path, "abort", {"SPP_DAG_TIMEOUT_TICKS": "1"})
+    assert np.array_equal(x_abort, x_levels)
