@@ -130,7 +130,7 @@ def main():
         torch.cuda.set_stream(torch.cuda.Stream())
 
     # N > 1: how the packed partial systems are summed (see Job.reduce_packed)
-    collective = ["direct" if (world > 1 and args.backend == "nccl" and args.collective == "direct") else "allreduce"]
+    collective = ["direct" if (world > 1 and args.collective == "direct") else "allreduce"]
 
     class Job:
         """one Lambda resident in HBM + everything a numeric solve needs; shard = (rank, world) of the landmark sharding"""
@@ -157,32 +157,13 @@ def main():
             self.S = self.P = None
             if self.schur and world > 1:
                 self.S = torch.empty(ctx.schur_buffer_size(), dtype=torch.float64, device="cuda")
-                npk = ctx.schur_packed_size()
-                npad = (npk + world - 1) // world * world  # equal slices for the direct exchange (the tail is zero)
-                self.Pfull = torch.zeros(npad, dtype=torch.float64, device="cuda")
-                self.P = self.Pfull  # upper trapezoid only (+ padding)
-                self.Precv = torch.empty(npad, dtype=torch.float64, device="cuda")
-                self.Pown = torch.empty(npad // world, dtype=torch.float64, device="cuda")
+                from slam_plus_plus_amd.exchange import PackedExchange
+                self.xch = PackedExchange(ctx.schur_packed_size(), world, "cuda", collective[0])
+                self.P = self.xch.buf  # upper trapezoid only (+ padding to equal slices)
 
         def reduce_packed(self):
-            """Sum of the ranks' packed partial systems, the result on every rank. xGMI is point to point (7 links per GPU):
-            `direct` = reduce-scatter as ONE all-to-all (every rank sends slice j of its buffer to rank j over their own
-            link: 1/N of the buffer per link, all links at once), a local in-order sum of the N slices, an all-gather of the
-            summed slices -- 2 x (buffer / N) per link instead of the ring all-reduce's 2 (N-1)/N x buffer over one.
-            Deterministic: slice j is summed in rank order on rank j. Falls back to all_reduce (gloo has no all-to-all)."""
-            P = self.P
-            if collective[0] == "direct":
-                try:
-                    n = P.numel() // world
-                    torch.cuda.current_stream()  # (collectives are ordered against the current stream)
-                    dist.all_to_all_single(self.Precv, P)
-                    torch.sum(self.Precv.view(world, n), dim=0, out=self.Pown)
-                    dist.all_gather_into_tensor(P, self.Pown)
-                    return
-                except Exception as e:  # noqa: BLE001 -- never take the measurement down: ring all-reduce instead
-                    collective[0] = "allreduce"
-                    collective.append("direct exchange failed (%r): ring all-reduce" % (e,))
-            dist.all_reduce(P)
+            """sum of the ranks' packed partial systems, the result on every rank (slam_plus_plus_amd/exchange.py)"""
+            self.xch.sum()
 
         def assemble(self):
             d = self.d_in
@@ -597,6 +578,22 @@ def main():
                                                       "cholmod": "CLinearSolver_CholMod", "csparse": "CLinearSolver_CSparse"}[backend],
                                                      args.cpu_solves, min(secs)),
                                        "rel_diff_gpu_vs_reference": float(np.linalg.norm(x - xr) / np.linalg.norm(xr))}
+                # the REAL adapter at this size (part of the reference-side leg: oracle/_ref/dropin_driver is the reference's
+                # CUberBlockMatrix + include/spp_adapter.h): Flatten_Values over 3.2 M blocks with up to 16 host threads
+                drv = os.path.join(ROOT, "oracle", "_ref", "dropin_driver")
+                if schur and os.path.exists(drv) and "nc" in prob and isinstance(out.get("dropin_ms"), dict):
+                    import subprocess
+                    track = max(2, int(round(prob.v0.size / max(1, prob.npts))))
+                    r = subprocess.run([drv, "adapter", str(prob.nc), str(prob.npts), str(track)], capture_output=True, text=True, timeout=600)
+                    f = dict(zip(r.stdout.split()[1::2], r.stdout.split()[2::2])) if r.returncode == 0 else {}
+                    if f:
+                        out["dropin_ms"]["adapter"] = {
+                            "flatten_ms": float(f["flatten_ms"]), "factor_solve_ms": float(f["factor_solve_ms"]),
+                            "threads": int(f["threads"]), "lambda_mb": float(f["lambda_mb"]), "blocks": int(f["blocks"]),
+                            "rel_residual": float(f["rel_residual"]),
+                            "what": "CLinearSolver_HIP::Solve_PosDef_Blocky on a CUberBlockMatrix of this shape (%s poses, %s landmarks, "
+                                    "%d observers each) built through the reference's container: Flatten_Values + spp_factor_solve" % (
+                                        f["cams"], f["points"], track)}
                 out["cpu_baseline"]["headline_backend"] = (
                     "the reference's FASTEST path for this workload (%s); north_star's CHOLMOD path is the `cholmod` entry" % backend)
                 # ---- north_star's CPU path: CLinearSolver_CholMod (src/slam/LinearSolver_CholMod.cpp:264-358: analyze + factorize
@@ -658,8 +655,8 @@ def main():
                     "rel_diff_gpu_vs_cholmod": float(np.linalg.norm(xs - xc) / np.linalg.norm(xc))}
         except Exception as e:  # noqa: BLE001
             out["cpu_baseline"] = {"value": None, "unit": "block-nnz/s", "cores": 1, "kind": "reference", "sample": "failed: %r" % (e,)}
-    if collective[0] != "allreduce" or len(collective) > 1:
-        out["config"]["collective"] = " / ".join(collective)
+    if world > 1 and job.S is not None:
+        out["config"]["collective"] = " / ".join([job.xch.mode] + job.xch.notes)
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -43,6 +43,7 @@
 #include <cstdlib>
 #include <algorithm>
 #include <thread>
+#include <chrono>
 
 #include "slam/LinearSolverTags.h" // CBlockwiseLinearSolverTag, CUberBlockMatrix, Eigen
 #include "spp_hip.h"
@@ -60,17 +61,18 @@ protected:
 	std::vector<int32_t> m_dim;
 	double *m_p_vals; /**< flattened block values: page-locked memory owned by the ctx (spp_host_staging) */
 	size_t m_n_vals;
+	double m_f_flatten_ms, m_f_solve_ms; /**< timing of the last solve (diagnostics) */
 
 public:
 	inline CLinearSolver_HIP(int n_device = 0, int n_mode = SPP_MODE_AUTO)
 		:m_p_ctx(0), m_n_device(n_device), m_n_mode(n_mode), m_b_have_symbolic(false),
-		m_n_sym_blocks(0), m_n_sym_cols(0), m_p_vals(0), m_n_vals(0)
+		m_n_sym_blocks(0), m_n_sym_cols(0), m_p_vals(0), m_n_vals(0), m_f_flatten_ms(0), m_f_solve_ms(0)
 	{}
 
 	/** copies configuration only, never state (LinearSolver_UberBlock.h:74-76) */
 	inline CLinearSolver_HIP(const CLinearSolver_HIP &r_other)
 		:m_p_ctx(0), m_n_device(r_other.m_n_device), m_n_mode(r_other.m_n_mode),
-		m_b_have_symbolic(false), m_n_sym_blocks(0), m_n_sym_cols(0), m_p_vals(0), m_n_vals(0)
+		m_b_have_symbolic(false), m_n_sym_blocks(0), m_n_sym_cols(0), m_p_vals(0), m_n_vals(0), m_f_flatten_ms(0), m_f_solve_ms(0)
 	{}
 
 	inline ~CLinearSolver_HIP()
@@ -117,13 +119,22 @@ public:
 			if(!SymbolicDecomposition_Blocky(r_lambda))
 				return false;
 		}
+		const std::chrono::steady_clock::time_point t_0 = std::chrono::steady_clock::now();
 		if(!Flatten_Values(r_lambda)) { // same counts, different structure: the stored symbolic decomposition is stale
 			if(!SymbolicDecomposition_Blocky(r_lambda) || !Flatten_Values(r_lambda))
 				throw std::runtime_error("libspp_hip adapter: the block structure of lambda changed while it was flattened");
 		}
+		const std::chrono::steady_clock::time_point t_1 = std::chrono::steady_clock::now();
 		int n_result = Check(spp_factor_solve(m_p_ctx, m_p_vals, r_eta.data()));
+		m_f_flatten_ms = std::chrono::duration<double>(t_1 - t_0).count() * 1e3;
+		m_f_solve_ms = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_1).count() * 1e3;
 		return n_result == SPP_OK; // SPP_NOT_POSDEF leaves eta untouched, like the reference
 	}
+
+	/** wall clock of the last Solve_PosDef_Blocky(): copying the blocks of lambda into the staging buffer / spp_factor_solve() */
+	inline double f_Last_Flatten_ms() const { return m_f_flatten_ms; }
+	inline double f_Last_Solve_ms() const { return m_f_solve_ms; }
+	inline size_t n_Staged_Bytes() const { return m_n_vals * sizeof(double); }
 
 	bool Solve_PosDef(const CUberBlockMatrix &r_lambda, Eigen::VectorXd &r_eta) // throw(std::bad_alloc, std::runtime_error)
 	{

@@ -30,6 +30,8 @@
 #include <math.h>
 #include <string.h>
 #include <vector>
+#include <thread>
+#include <algorithm>
 
 #include "slam/LinearSolver_UberBlock.h"
 #include "slam/ConfigSolvers.h"
@@ -206,8 +208,92 @@ static int Compare(const char *p_s_what, size_t a, size_t b, const std::vector<d
 	return (f_max <= f_tol * std::max(1.0, f_norm))? 0 : 1;
 }
 
+/**
+ *	@brief the adapter at scale: a bundle-adjustment-shaped Lambda (n_cams 6 x 6 poses first, n_points 3 x 3 landmarks,
+ *		every point seen by n_track consecutive cameras of a sliding window) built directly as a CUberBlockMatrix through
+ *		its public interface, diagonally dominant values; CLinearSolver_HIP::Solve_PosDef_Blocky() then walks every block
+ *		(Flatten_Values, up to 16 host threads) and solves. Prints what the boundary costs per call; checks the residual.
+ */
+static int Time_Adapter(size_t n_cams, size_t n_points, size_t n_track)
+{
+	const size_t nb = n_cams + n_points;
+	std::vector<size_t> cumsum(nb);
+	for(size_t i = 0, n_sum = 0; i < nb; ++ i)
+		cumsum[i] = (n_sum += (i < n_cams)? 6 : 3);
+	CUberBlockMatrix lambda(cumsum.begin(), cumsum.end(), cumsum.begin(), cumsum.end());
+	const size_t n = cumsum.back();
+	size_t n_blocks = 0, n_seed = 12345;
+	struct TRand { static double f(size_t &r_s) { r_s = r_s * 6364136223846793005ull + 1442695040888963407ull; return double((r_s >> 33) & 0xffffff) / double(0xffffff) - .5; } };
+	for(size_t i = 0; i < n_cams; ++ i) { // camera diagonal blocks: strongly dominant
+		double *p_b = lambda.p_FindBlock((i)? cumsum[i - 1] : 0, (i)? cumsum[i - 1] : 0, 6, 6, true, true);
+		if(!p_b)
+			return 2;
+		for(int c = 0; c < 6; ++ c)
+			for(int r = 0; r < 6; ++ r)
+				p_b[r + 6 * c] = (r == c)? 50.0 * double(n_track) * double(n_points) / double(n_cams) : 0.0;
+		++ n_blocks;
+	}
+	for(size_t j = 0; j < n_points; ++ j) {
+		const size_t n_col = cumsum[n_cams + j - 1];
+		const size_t n_first = (j * 7919) % (n_cams - n_track + 1); // the track's window
+		for(size_t t = 0; t < n_track; ++ t) {
+			double *p_b = lambda.p_FindBlock((n_first + t)? cumsum[n_first + t - 1] : 0, n_col, 6, 3, true, true);
+			if(!p_b)
+				return 2;
+			for(int e = 0; e < 18; ++ e)
+				p_b[e] = TRand::f(n_seed);
+			++ n_blocks;
+		}
+		double *p_d = lambda.p_FindBlock(n_col, n_col, 3, 3, true, true);
+		if(!p_d)
+			return 2;
+		for(int c = 0; c < 3; ++ c)
+			for(int r = 0; r < 3; ++ r)
+				p_d[r + 3 * c] = (r == c)? 20.0 * double(n_track) : 0.0;
+		++ n_blocks;
+	}
+	Eigen::VectorXd v_rhs(n), v_x;
+	for(size_t i = 0; i < n; ++ i)
+		v_rhs(i) = TRand::f(n_seed);
+	CLinearSolver_HIP solver;
+	double f_best_flat = 1e30, f_best_solve = 1e30;
+	for(int n_pass = 0; n_pass < 4; ++ n_pass) {
+		v_x = v_rhs;
+		if(!solver.Solve_PosDef_Blocky(lambda, v_x)) {
+			fprintf(stderr, "error: the factorization failed\n");
+			return 2;
+		}
+		if(n_pass) { // (the first call carries the symbolic analysis)
+			f_best_flat = std::min(f_best_flat, solver.f_Last_Flatten_ms());
+			f_best_solve = std::min(f_best_solve, solver.f_Last_Solve_ms());
+		}
+	}
+	// residual of the full symmetric system from its upper triangle
+	Eigen::VectorXd v_r = -v_rhs;
+	for(size_t i = 0, n_col_num = lambda.n_BlockColumn_Num(); i < n_col_num; ++ i) {
+		const size_t n_c0 = lambda.n_BlockColumn_Base(i), n_cw = lambda.n_BlockColumn_Column_Num(i);
+		for(size_t k = 0, m = lambda.n_BlockColumn_Block_Num(i); k < m; ++ k) {
+			const size_t n_row = lambda.n_Block_Row(i, k);
+			if(n_row > i)
+				continue;
+			CUberBlockMatrix::_TyConstMatrixXdRef t_b = ((const CUberBlockMatrix&)lambda).t_Block_AtColumn(i, k);
+			const size_t n_r0 = lambda.n_BlockRow_Base(n_row);
+			v_r.segment(n_r0, t_b.rows()) += t_b * v_x.segment(n_c0, n_cw);
+			if(n_row != i)
+				v_r.segment(n_c0, n_cw) += t_b.transpose() * v_x.segment(n_r0, t_b.rows());
+		}
+	}
+	const double f_res = v_r.norm() / v_rhs.norm();
+	printf("adapter cams %lu points %lu blocks %lu lambda_mb %.1f flatten_ms %.2f factor_solve_ms %.2f threads %u rel_residual %.3e\n",
+		(unsigned long)n_cams, (unsigned long)n_points, (unsigned long)n_blocks, solver.n_Staged_Bytes() * 1e-6, f_best_flat,
+		f_best_solve, (unsigned)std::min(16u, std::max(1u, std::thread::hardware_concurrency())), f_res);
+	return (f_res < 1e-10)? 0 : 1;
+}
+
 int main(int n_arg_num, const char **p_arg_list)
 {
+	if(n_arg_num > 4 && !strcmp(p_arg_list[1], "adapter"))
+		return Time_Adapter(atol(p_arg_list[2]), atol(p_arg_list[3]), atol(p_arg_list[4]));
 	if(n_arg_num > 1 && !strcmp(p_arg_list[1], "ba")) {
 		size_t n_cams = (n_arg_num > 2)? atol(p_arg_list[2]) : 12;
 		size_t n_points = (n_arg_num > 3)? atol(p_arg_list[3]) : 300;

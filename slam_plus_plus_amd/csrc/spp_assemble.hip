@@ -193,7 +193,7 @@ void assemble_analyze(spp_ctx *ctx, int64_t nv, const int32_t *dim, int64_t ne, 
 	}
 	clk.lap("vertex lists");
 	hipStream_t s = ctx->stream;
-	UploadArena arena;
+	UploadArena arena(s);
 	arena.add(ap->ob_ptr, ob_ptr);
 	arena.add(ap->ob_edge, ob_edge);
 	arena.add(ap->ob_off, ob_off);
@@ -210,7 +210,7 @@ void assemble_analyze(spp_ctx *ctx, int64_t nv, const int32_t *dim, int64_t ne, 
 		arena.add(ap->vlist_seq[cls], lseq[cls]);
 		arena.add(ap->vlist_wave[cls], lwave[cls]);
 	}
-	arena.commit(ap->index_store, s);
+	arena.commit(ap->index_store);
 	SPP_HIP_CHECK(hipStreamSynchronize(s));
 	clk.lap("uploads");
 	// complete: install. The ctx now describes this Lambda (sizes for spp_get_info before spp_analyze is called);

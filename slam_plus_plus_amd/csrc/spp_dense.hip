@@ -299,9 +299,11 @@ static bool launch_gemm_mixed(hipStream_t s, int64_t M, int64_t N, int K, const 
 	if(use444 < 0) {
 		const char *e = getenv("SPP_TILE_444"); // whole 128 x 128 tiles: 0 register-staged 16x16x4 tile (rounds 1-2, default), 1 LDS-DMA 16x16x4 tile, 2 LDS-DMA 4x4x4_4b tile
 		use444 = e ? atoi(e) : 0;
+	}
+	static uint64_t mixed_attr_seen = 0;
+	if(first_on_this_device(mixed_attr_seen))
 		SPP_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tn_mixed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
 			T444_LDS_DOUBLES * (int)sizeof(double)));
-	}
 	const size_t lds = use444 ? (size_t)T444_LDS_DOUBLES * sizeof(double)
 		: (size_t)(128 + 128) * 18 * sizeof(double); // >= (64 + 64) * 34 doubles of the quarter path
 	hipLaunchKernelGGL(gemm_tn_mixed_kernel, dim3((unsigned)grid), dim3(1024), lds, s,
@@ -325,11 +327,10 @@ static void launch_gemm(hipStream_t s, int64_t M, int64_t N, int K, const double
 		pad = e ? (size_t)atol(e) : 0;
 	}
 	const size_t lds = (size_t)(BM + BN) * (BKT + 2) * sizeof(double) + pad;
-	static bool attr = false;
-	if(!attr && lds > 65536) {
+	static uint64_t attr_seen = 0;
+	if(lds > 65536 && first_on_this_device(attr_seen)) {
 		SPP_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tn_kernel<BM, BN, WM, WN, MODE, DEPTH, MINW, BKT>,
 			hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-		attr = true;
 	}
 	SPP_REQUIRE(K % BKT == 0, SPP_E_BADARG, "gemm: K must be a multiple of the slab depth");
 	hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, WM, WN, MODE, DEPTH, MINW, BKT>), grid, block, lds, s,
@@ -415,12 +416,11 @@ template <int BM, int BN, int WM, int WN, int MODE, int ATRI = 0>
 static void launch_gemm_staged(hipStream_t s, int64_t M, int64_t N, int K, const double *A, int64_t lda,
 	const double *B, int64_t ldb, double *C, int64_t ldc, bool upper_only)
 {
-	static bool attr = false;
+	static uint64_t attr_seen = 0;
 	const size_t lds = (size_t)(BM + BN) * FS_STRIDE * sizeof(double);
-	if(!attr) {
+	if(first_on_this_device(attr_seen)) {
 		SPP_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tn_staged_kernel<BM, BN, WM, WN, MODE, ATRI>,
 			hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-		attr = true;
 	}
 	SPP_REQUIRE(K == FS_KMAX, SPP_E_BADARG, "staged gemm: K must be 128");
 	dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
@@ -819,11 +819,10 @@ static void ensure_dense_work(spp_ctx *ctx, int64_t nblk)
 		SPP_HIP_CHECK(hipEventCreateWithFlags(&ctx->dense.ev[0], hipEventDisableTiming));
 		SPP_HIP_CHECK(hipEventCreateWithFlags(&ctx->dense.ev[1], hipEventDisableTiming));
 	}
-	static bool attr_set = false;
-	if(!attr_set) {
+	static uint64_t attr_set_seen = 0;
+	if(first_on_this_device(attr_set_seen)) {
 		SPP_HIP_CHECK(hipFuncSetAttribute((const void*)potrf_diag_kernel,
 			hipFuncAttributeMaxDynamicSharedMemorySize, POTRF_LDS_DOUBLES * (int)sizeof(double)));
-		attr_set = true;
 	}
 }
 
@@ -898,11 +897,10 @@ static void la_setup_streams(spp_ctx *ctx)
 		SPP_HIP_CHECK(hipMemset(dw.info.p + 2, 0, sizeof(int)));
 		return;
 	}
-	static bool attr = false;
-	if(!attr) {
+	static uint64_t attr_seen = 0;
+	if(first_on_this_device(attr_seen)) {
 		SPP_HIP_CHECK(hipFuncSetAttribute((const void*)la_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
 			LA_LDS_DOUBLES * (int)sizeof(double)));
-		attr = true;
 	}
 	dw.la_state = 1;
 }
@@ -960,9 +958,11 @@ static void dense_factor_lookahead(spp_ctx *ctx, double *d_A, int64_t ld, int64_
 		if(u < 0) {
 			const char *e = getenv("SPP_TILE_444");
 			u = e ? atoi(e) : 0;
+		}
+		static uint64_t bulk_attr_seen = 0;
+		if(first_on_this_device(bulk_attr_seen))
 			SPP_HIP_CHECK(hipFuncSetAttribute((const void*)la_bulk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
 				LA_BULK_LDS_DOUBLES * (int)sizeof(double)));
-		}
 		a.use444 = u;
 	}
 	a.trace = nullptr;
@@ -1206,11 +1206,10 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 	}
 	const int fused = allow_fused ? fused_env : 0; // (its sub-tile counters are monotonic: not inside a stream capture)
 	if(fused) {
-		static bool fattr = false;
-		if(!fattr) {
+		static uint64_t fattr_seen = 0;
+		if(first_on_this_device(fattr_seen)) {
 			SPP_HIP_CHECK(hipFuncSetAttribute((const void*)update_potrf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
 				POTRF_LDS_DOUBLES * (int)sizeof(double)));
-			fattr = true;
 		}
 		// per-step counters of finished diagonal sub-tiles: monotonic, never reset between factorizations (the host keeps
 		// the value each slot will have reached) -- a memset per call was a 4.5 us launch in front of every big front

@@ -28,6 +28,19 @@ struct Error : std::runtime_error {
 	throw spp::Error(SPP_E_HIP, std::string(#expr " failed: ") + hipGetErrorString(e_)); } while(0)
 #define SPP_REQUIRE(cond, code, msg) do { if(!(cond)) throw spp::Error((code), (msg)); } while(0)
 
+// hipFuncSetAttribute is per DEVICE: true the first time the calling site runs on the current device (a process may hold
+// contexts on several GPUs)
+inline bool first_on_this_device(uint64_t &seen)
+{
+	int dev = 0;
+	(void)hipGetDevice(&dev);
+	const uint64_t bit = uint64_t(1) << (dev & 63);
+	if(seen & bit)
+		return false;
+	seen |= bit;
+	return true;
+}
+
 // wall clock of the host-side phases of an analysis, printed lap by lap when SPP_VERBOSE is set
 struct VClock {
 	const char *who;
@@ -98,12 +111,18 @@ struct DevBuf {
 // (26 arrays: 10-18 ms of a 14 ms sparse_analyze). add() stages a vector, commit() uploads everything and turns the
 // DevBufs into views of the allocation `store` owns; the host image must live until the stream has been synchronized.
 struct UploadArena {
+	hipStream_t stream;
 	std::vector<unsigned char> host;
 	struct Item { void **pp; size_t *pcap; bool *powned; size_t off, n; };
 	std::vector<Item> items;
+	explicit UploadArena(hipStream_t s) : stream(s) { host.reserve(size_t(1) << 20); }
 	template <class T>
 	void add(DevBuf<T> &b, const std::vector<T> &v)
 	{
+		if(v.size() * sizeof(T) > (size_t(256) << 10)) { // a large array gains nothing from being staged twice: its own upload
+			b.upload(v, stream);
+			return;
+		}
 		b.release();
 		const size_t off = (host.size() + 255) & ~(size_t)255, bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
 		host.resize(off + bytes);
@@ -112,11 +131,12 @@ struct UploadArena {
 		Item it = {(void**)&b.p, &b.cap, &b.owned, off, std::max<size_t>(v.size(), 1)};
 		items.push_back(it);
 	}
-	void commit(DevBuf<unsigned char> &store, hipStream_t s)
+	void commit(DevBuf<unsigned char> &store)
 	{
 		store.release();
 		store.reserve(std::max<size_t>(host.size(), 256));
-		SPP_HIP_CHECK(hipMemcpyAsync(store.p, host.data(), host.size(), hipMemcpyHostToDevice, s));
+		if(!host.empty())
+			SPP_HIP_CHECK(hipMemcpyAsync(store.p, host.data(), host.size(), hipMemcpyHostToDevice, stream));
 		for(size_t i = 0; i < items.size(); ++ i) {
 			*items[i].pp = store.p + items[i].off;
 			*items[i].pcap = items[i].n;

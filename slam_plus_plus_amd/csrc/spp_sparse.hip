@@ -735,7 +735,7 @@ void sparse_analyze(spp_ctx *ctx, const Structure &st)
 			}
 	}
 	hipStream_t s = ctx->stream;
-	UploadArena arena;
+	UploadArena arena(s);
 	arena.add(sp->level_fronts, sp->h_level_fronts);
 	arena.add(sp->front_off, front_off);
 	arena.add(sp->front_h, front_h);
@@ -762,7 +762,7 @@ void sparse_analyze(spp_ctx *ctx, const Structure &st)
 	arena.add(sp->dag_rank, dag_rank);
 	arena.add(sp->front_team, front_team);
 	arena.add(sp->front_tinv, front_tinv);
-	arena.commit(sp->index_store, s);
+	arena.commit(sp->index_store);
 	sp->team_tinv.reserve((size_t)std::max<int64_t>(tinv_doubles, 1));
 	sp->team_bar.reserve((size_t)std::max<int64_t>(ns, 1));
 	SPP_HIP_CHECK(hipMemsetAsync(sp->team_bar.p, 0, (size_t)std::max<int64_t>(ns, 1) * sizeof(int), s));
@@ -1611,11 +1611,10 @@ static void launch_front_lds(spp_ctx *ctx, SparsePlan *sp, int32_t b, int32_t e,
 	if(e <= b)
 		return;
 	const size_t lds = ((GMEM ? (size_t)17 * HP : (size_t)HP * (HP + 1)) + 2 * 16 * PT + HP + 8) * sizeof(double);
-	static bool attr = false;
-	if(!attr) {
+	static uint64_t attr_seen = 0;
+	if(first_on_this_device(attr_seen)) {
 		SPP_HIP_CHECK(hipFuncSetAttribute((const void*)front_lds_kernel<HP, NTH, GMEM>,
 			hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-		attr = true;
 	}
 	hipLaunchKernelGGL((front_lds_kernel<HP, NTH, GMEM>), dim3((unsigned)(e - b)), dim3(NTH), lds, ctx->stream,
 		sp->level_fronts.p + b, make_front_args(ctx, sp, d_vals));
@@ -1683,11 +1682,10 @@ static void sparse_enqueue(spp_ctx *ctx, const double *d_vals, double *d_rhs)
 	da.solve_index = 0;
 	da.trace = nullptr;
 	if(dag) {
-		static bool attr = false;
-		if(!attr) {
+		static uint64_t attr_seen = 0;
+		if(first_on_this_device(attr_seen)) {
 			SPP_HIP_CHECK(hipFuncSetAttribute((const void*)front_dag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
 				(int)(std::max<size_t>(std::max<size_t>((size_t)17 * MID_FRONT_MAX + MID_FRONT_MAX, (size_t)128 * 129 + 128) + 2 * 16 * PT + 8, TEAM_LDS_DOUBLES) * sizeof(double))));
-			attr = true;
 		}
 		if(sp->dag_solves >= (1 << 18) || sp->dag_epoch >= (1 << 30)) {
 			// the teams' barrier counters and the fronts' epochs are monotonic 32-bit words (solve_index * G * barriers per

@@ -61,6 +61,12 @@ def _write_app_graphs(tmp):
     o = np.stack([st["pt_of"].astype(float), st["cam_of"].astype(float), st["meas"][:, 0], st["meas"][:, 1]], axis=1)
     out["ba"] = os.path.join(tmp, "ba_small.txt")
     formats.save_ba_graph(out["ba"], st["cams"], st["intr"], st["points"], o)
+    # BASELINE config 3 shape (Ladybug-49: 49 cameras, 7 776 points, 31 843 observations) for the applications
+    p = synth.make("ladybug49")
+    st = synth.ba_states(p)
+    o = np.stack([st["pt_of"].astype(float), st["cam_of"].astype(float), st["meas"][:, 0], st["meas"][:, 1]], axis=1)
+    out["ladybug"] = os.path.join(tmp, "ladybug49.txt")
+    formats.save_ba_graph(out["ladybug"], st["cams"], st["intr"], st["points"], o)
     return out
 
 
@@ -91,6 +97,10 @@ def pytest_sessionstart(session):
                             ("slam_simple_hip", "slam_simple_hip", [])):
         with tempfile.TemporaryDirectory() as tmp:
             run(key, name, args, tmp)
+    # the adapter on a Venice-sized CUberBlockMatrix (871 poses, 530 304 landmarks, 2.65 M pose-landmark blocks, 420 MB):
+    # Flatten_Values with up to 16 host threads + the host-pointer solve, timed by the adapter itself
+    with tempfile.TemporaryDirectory() as tmp:
+        run("dropin_adapter_scale", "dropin_driver", ["adapter", "871", "530304", "5"], tmp)
     # the adapter's threaded flatten (taken by itself from 32 MB of Lambda on) forced onto a small system
     with tempfile.TemporaryDirectory() as tmp:
         run("dropin_driver_ba_mt", "dropin_driver", ["ba", "16", "600", "1"], tmp, {"SPP_ADAPTER_FLATTEN_THREADS": "5"})
@@ -100,7 +110,7 @@ def pytest_sessionstart(session):
     if os.path.exists(os.path.join(ref_dir, "slam_plus_plus_hip")):
         with tempfile.TemporaryDirectory() as gdir:
             graphs = _write_app_graphs(gdir)
-            for kind, extra in (("se2", ["-po"]), ("se3", ["-po"]), ("ba", []), ("ba_us", ["-us"])):
+            for kind, extra in (("se2", ["-po"]), ("se3", ["-po"]), ("ba", []), ("ba_us", ["-us"]), ("ladybug", [])):
                 g = graphs[kind.split("_")[0]]
                 for which in ("hip", "ref"):
                     with tempfile.TemporaryDirectory() as tmp:

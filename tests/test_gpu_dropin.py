@@ -49,6 +49,21 @@ def test_threaded_flatten_of_the_adapter_gives_the_same_result():
     assert out == DROPIN_RESULTS["dropin_driver_ba"][1], "one thread and five threads must flatten the same Lambda"
 
 
+def test_adapter_flattens_and_solves_a_venice_sized_block_matrix():
+    """include/spp_adapter.h at the size the metric is quoted on: a CUberBlockMatrix with 871 pose and 530 304 landmark
+    block columns (2.65 M pose-landmark blocks, 420 MB of values) built through the reference's own container;
+    CLinearSolver_HIP::Solve_PosDef_Blocky walks every block with up to 16 host threads, the library solves from the
+    page-locked staging buffer. The driver checks the residual of the full system and prints what the boundary costs."""
+    if "dropin_adapter_scale" not in DROPIN_RESULTS:
+        pytest.skip("oracle/_ref/dropin_driver not built")
+    rc, out, err, _ = DROPIN_RESULTS["dropin_adapter_scale"]
+    assert rc == 0, (rc, out, err)
+    f = dict(zip(out.split()[1::2], out.split()[2::2]))
+    assert int(f["blocks"]) == 871 + 530304 + 5 * 530304 and float(f["lambda_mb"]) > 400
+    assert float(f["rel_residual"]) < 1e-10
+    assert 0 < float(f["flatten_ms"]) < 2000 and 0 < float(f["factor_solve_ms"]) < 2000, out
+
+
 def test_unmodified_slam_simple_example_runs_on_the_hip_solver():
     if "slam_simple_hip" not in DROPIN_RESULTS:
         pytest.skip("oracle/_ref/slam_simple_hip not built")
@@ -69,7 +84,7 @@ def _app_summary(out):
     return int(it[-1]), float(chi2[-1]), res
 
 
-@pytest.mark.parametrize("kind", ["se2", "se3", "ba", "ba_us"])
+@pytest.mark.parametrize("kind", ["se2", "se3", "ba", "ba_us", "ladybug"])
 def test_unmodified_slam_plus_plus_app_on_the_hip_solver_matches_the_reference_binary(kind):
     """`slam_plus_plus` = every source file of src/slam_app, byte-identical, compiled with
     -D__LINEAR_SOLVER_OVERRIDE=3 (the reference's own switch for CLinearSolver_UberBlock, Config.h:90-109) once with

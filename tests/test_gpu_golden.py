@@ -17,6 +17,10 @@ def _rel(a, b):
     return np.linalg.norm(a - b) / np.linalg.norm(b)
 
 
+# pose graphs anchored by one unit prior (cond 1e7 .. 1e11): direct bound on ||dx - dx_ref|| / ||dx_ref|| per fixture
+DIRECT_BOUND = {"se2_small": 2e-8, "se3_small": 2e-8, "manhattan3500": 1e-6, "sphere2500": 5e-9}
+
+
 @pytest.mark.parametrize("name", ["ba_tiny", "ba_small", "ba_interleaved", "ladybug49", "se2_small", "se3_small",
                                   "manhattan3500", "sphere2500"])
 def test_hip_solution_matches_reference_golden(name):
@@ -36,6 +40,13 @@ def test_hip_solution_matches_reference_golden(name):
     # of the same Lambda (tests/parity.py; on the pose graphs the reference's own backends are 1e-9..1e-7 away from it)
     import parity
     parity.check_against_reference(x, g, lam, eta)
+    # ... and the plain relative difference to every stored reference solution, with an explicit bound per fixture (about
+    # three times what was measured on MI355X: manhattan3500 3.0e-7, sphere2500 1.4e-9 against CLinearSolver_UberBlock): a
+    # regression that stays inside the yardstick's 4x slack still shows here
+    if name in DIRECT_BOUND:
+        for key in g.files:
+            if key.startswith("dx_") and key != "dx_stride":
+                assert _rel(x[::stride], g[key]) < DIRECT_BOUND[name], (key, _rel(x[::stride], g[key]))
 
 
 def test_venice_full_size_properties():

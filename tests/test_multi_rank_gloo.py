@@ -64,3 +64,45 @@ def test_two_rank_landmark_sharding_reproduces_the_full_solve(name):
     mp.spawn(_worker, args=(world, _free_port(), name, ret), nprocs=world, join=True)
     assert ret["rel"] < 1e-10, ret["rel"]
     assert abs(ret["shards"][0] - ret["shards"][1]) <= 1  # round-robin balance
+
+
+def _xch_worker(rank, world, port, numel, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from slam_plus_plus_amd.exchange import PackedExchange
+    rng = np.random.default_rng(100 + rank)
+    mine = rng.standard_normal(numel)
+    out = {}
+    for mode in ("direct", "allreduce"):
+        x = PackedExchange(numel, world, "cpu", mode)
+        assert x.padded % world == 0 and x.padded >= numel
+        for _ in range(2):  # twice: the buffers are reused call after call
+            x.buf.zero_()
+            x.buf[:numel] = torch.from_numpy(mine)
+            x.sum()
+        out[mode] = (x.buf.numpy().copy(), x.mode, list(x.notes))
+    want = sum(np.random.default_rng(100 + r).standard_normal(numel) for r in range(world))
+    gathered = [None] * world
+    dist.all_gather_object(gathered, out["direct"][0][:numel].tobytes())
+    if rank == 0:
+        ret["direct_mode"] = out["direct"][1]
+        ret["err_direct"] = float(np.abs(out["direct"][0][:numel] - want).max())
+        ret["err_allreduce"] = float(np.abs(out["allreduce"][0][:numel] - want).max())
+        ret["tail_zero"] = bool(np.all(out["direct"][0][numel:] == 0))
+        ret["same_on_all_ranks"] = all(g == gathered[0] for g in gathered)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,numel", [(2, 1001), (3, 4096)])
+def test_direct_exchange_equals_the_all_reduce(world, numel):
+    """slam_plus_plus_amd/exchange.py (what bench.py --gpus N runs over RCCL): reduce-scatter as one all-to-all + local
+    sum in rank order + all-gather gives the all-reduce's sum, identical bits on every rank, also when the buffer does
+    not divide by the number of ranks (zero padding)"""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_xch_worker, args=(world, _free_port(), numel, ret), nprocs=world, join=True)
+    assert ret["direct_mode"] == "direct", "gloo offers all_to_all_single on CPU tensors: the direct path must have run"
+    assert ret["err_direct"] < 1e-13 and ret["err_allreduce"] < 1e-13
+    assert ret["tail_zero"] and ret["same_on_all_ranks"]
