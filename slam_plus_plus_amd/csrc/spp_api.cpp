@@ -152,10 +152,6 @@ void spp_destroy(spp_ctx *ctx)
 		(void)hipEventDestroy(ctx->dense.ev[0]);
 		(void)hipEventDestroy(ctx->dense.ev[1]);
 	}
-	if(ctx->dense.row) {
-		(void)hipStreamDestroy(ctx->dense.row);
-		(void)hipEventDestroy(ctx->dense.ev_row);
-	}
 	if(ctx->dense.chain) {
 		(void)hipStreamDestroy(ctx->dense.chain);
 		if(ctx->dense.ev_chain)

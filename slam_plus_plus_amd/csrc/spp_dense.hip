@@ -114,24 +114,6 @@ __device__ __forceinline__ void gemm_tn_tile(const int64_t m0, const int64_t n0,
 		*(double2*)(&As[(p / PPC) * LSTR + (p % PPC) * 2]) = (buf ? ra1 : ra0)[i]; } \
 	_Pragma("unroll") for(int i = 0; i < PB; ++ i) { int p = tid + i * NT; \
 		*(double2*)(&Bs[(p / PPC) * LSTR + (p % PPC) * 2]) = (buf ? rb1 : rb0)[i]; }
-#if SPP_MFMA_444
-	// v_mfma_f64_4x4x4_4b (four independent 4 x 4 x 4 products; lane maps in spp_dense_dev.h): measured on this part at one
-	// instruction (512 flop) per 18 cycles and SIMD = 72 TFLOP/s against one v_mfma_f64_16x16x4 (2048 flop) per 101 cycles =
-	// 48 TFLOP/s (tools/mfma_rate.hip). One instruction forms a 16 x 4 strip of C: the B operand is the 16x16x4 form's own
-	// (k = lane >> 4, 16 rows of C), the A operand four columns of C replicated over the four blocks; strip r of a
-	// 16 x 16 tile lands exactly where accumulator register r of the 16x16x4 form lives (n = 4 r + (lane >> 4)).
-#define SPP_COMPUTE_SLAB() \
-	_Pragma("unroll") for(int kk = 0; kk < BKT / 4; ++ kk) { \
-		double fa[TA]; \
-		_Pragma("unroll") for(int a = 0; a < TA; ++ a) fa[a] = As[(wm + a * 16 + l15) * LSTR + kk * 4 + l4]; \
-		_Pragma("unroll") for(int b = 0; b < TB; ++ b) \
-			_Pragma("unroll") for(int r = 0; r < 4; ++ r) { \
-				const double fb = Bs[(wn + b * 16 + 4 * r + (lane & 3)) * LSTR + kk * 4 + l4]; \
-				_Pragma("unroll") for(int a = 0; a < TA; ++ a) \
-					acc[b][a][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(fb, fa[a], acc[b][a][r], 0, 0, 0); \
-			} \
-	}
-#else
 #define SPP_COMPUTE_SLAB() \
 	_Pragma("unroll") for(int kk = 0; kk < BKT / 4; ++ kk) { \
 		double fa[TA], fb[TB]; \
@@ -141,7 +123,6 @@ __device__ __forceinline__ void gemm_tn_tile(const int64_t m0, const int64_t n0,
 			_Pragma("unroll") for(int a = 0; a < TA; ++ a) \
 				acc[b][a] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[b], fa[a], acc[b][a], 0, 0, 0); \
 	}
-#endif
 
 	if(DEPTH == 1) {
 		// one slab in flight (fewer staging registers: no scratch at 128 VGPRs, two workgroups per CU)
@@ -280,20 +261,12 @@ void gemm_tn_mixed_kernel(int64_t M, int64_t N, int K, const double *__restrict_
 static bool launch_gemm_mixed(hipStream_t s, int64_t M, int64_t N, int K, const double *A, int64_t lda,
 	const double *B, int64_t ldb, double *C, int64_t ldc)
 {
-	static int64_t slots = -1, whole_below = -1;
-	if(slots < 0) {
-		const char *e = getenv("SPP_MIX_SLOTS"); // concurrently resident 128 x 128 workgroups (2 per CU)
-		slots = e ? atol(e) : 512;
-		e = getenv("SPP_MIX_WHOLE_BELOW"); // launches with fewer tiles than this are not cut at all
-		whole_below = e ? atol(e) : 0;
-	}
-	if(slots == 0 || K % 32 != 0 || N < M)
+	const int64_t slots = 512; // concurrently resident 128 x 128 workgroups (2 per CU)
+	if(K % 32 != 0 || N < M)
 		return false;
 	const int64_t nt = (M + 127) / 128, ntc = (N + 127) / 128;
 	const int64_t T = nt * (nt + 1) / 2 + (ntc - nt) * nt;
-	int64_t n128 = (T / slots) * slots;
-	if(T < whole_below)
-		n128 = T;
+	const int64_t n128 = (T / slots) * slots;
 	const int64_t grid = n128 + 4 * (T - n128);
 	static int use444 = -1;
 	if(use444 < 0) {
@@ -319,14 +292,7 @@ static void launch_gemm(hipStream_t s, int64_t M, int64_t N, int K, const double
 	dim3 block((BM / WM) * (BN / WN) * 64);
 	if(!grid.x || !grid.y)
 		return;
-	// SPP_GEMM_LDS_PAD: extra dynamic LDS per workgroup = an occupancy limiter (e.g. 49152 leaves one
-	// 1024-thread workgroup per CU, so that the chain kernels of the other stream find wave slots)
-	static size_t pad = (size_t)-1;
-	if(pad == (size_t)-1) {
-		const char *e = getenv("SPP_GEMM_LDS_PAD");
-		pad = e ? (size_t)atol(e) : 0;
-	}
-	const size_t lds = (size_t)(BM + BN) * (BKT + 2) * sizeof(double) + pad;
+	const size_t lds = (size_t)(BM + BN) * (BKT + 2) * sizeof(double);
 	static uint64_t attr_seen = 0;
 	if(lds > 65536 && first_on_this_device(attr_seen)) {
 		SPP_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tn_kernel<BM, BN, WM, WN, MODE, DEPTH, MINW, BKT>,
@@ -438,56 +404,23 @@ bool dense_gemm_tn_sub(spp_ctx *ctx, int64_t m, int64_t n, int64_t k, const doub
 	SPP_REQUIRE(k % BK == 0, SPP_E_BADARG, "gemm_tn_sub: k must be a multiple of 16");
 	if(!m || !n || !k)
 		return false;
-	// 128 x 128 tiles when they fill the chip, 64 x 64 tiles for the tail of the factorization
+	// 128 x 128 tiles when they fill the chip, 64 x 64 tiles for the tail of the factorization; an upper update of at
+	// least 50 tiles goes through the mixed-granularity kernel (whole tiles first, the tail of the launch in quarters).
+	// (Measured and dropped in rounds 1-2: 64 x 32 / 32 x 64 wave tiles, two slabs in flight, 32- and 64-deep slabs,
+	// 128 x 64 and 256 x 128 workgroup tiles, an LDS pad as occupancy limiter -- DESIGN.md section 3.)
 	int64_t t128 = ((m + 127) / 128) * ((n + 127) / 128);
 	if(upper_only)
 		t128 = t128 / 2 + 1;
-	static int cfg = -1;
-	static int64_t mix_min_tiles = 192;
-	if(cfg < 0) {
-		const char *e = getenv("SPP_GEMM_CFG");
-		cfg = e ? atoi(e) : 9;
-		e = getenv("SPP_MIX_MIN_TILES"); // the mixed-granularity kernel takes every upper update of at least this many 128 x 128 tiles
-		mix_min_tiles = e ? atol(e) : 50;
-	}
-	if(t128 >= 192 && cfg == 1)
-		launch_gemm<128, 128, 64, 32, 0, 1>(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc, upper_only);
-	else if(t128 >= 192 && cfg == 4)
-		launch_gemm<128, 128, 64, 32, 0, 2, 2>(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc, upper_only);
-	else if(t128 >= 192 && cfg == 5)
-		launch_gemm<128, 128, 64, 32, 0, 1, 2>(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc, upper_only);
-	else if(t128 >= 192 && cfg == 6 && k % 32 == 0)
-		launch_gemm<128, 128, 64, 32, 0, 1, 2, 32>(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc, upper_only);
-	else if(t128 >= 192 && cfg == 7 && k % 32 == 0)
-		launch_gemm<128, 128, 64, 32, 0, 2, 2, 32>(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc, upper_only);
-	else if(t128 >= mix_min_tiles && cfg == 9 && upper_only && launch_gemm_mixed(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc))
-		return true;
-	else if(t128 >= 192 && cfg == 9) {
-		if(!upper_only || !launch_gemm_mixed(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc))
-			launch_gemm<128, 128, 32, 32, 0, 1, 1>(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc, upper_only);
-	}
-	else if(t128 >= 192 && cfg == 12 && k % 32 == 0)
-		launch_gemm<128, 128, 32, 32, 0, 1, 1, 32>(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc, upper_only);
-	else if(t128 >= 192 && cfg == 13)
-		launch_gemm<128, 128, 32, 32, 0, 2, 1>(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc, upper_only);
-	else if(t128 >= 192 && cfg == 14 && k % 64 == 0)
-		launch_gemm<128, 128, 32, 32, 0, 1, 1, 64>(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc, upper_only);
-	else if(t128 >= 192 && cfg == 10)
-		launch_gemm<128, 64, 32, 32, 0, 1, 1>(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc, upper_only);
-	else if(t128 >= 192 && cfg == 11)
-		launch_gemm<256, 128, 64, 32, 0, 1, 1>(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc, upper_only);
-	else if(t128 >= 192 && cfg == 8 && k % 64 == 0)
-		launch_gemm<128, 128, 64, 32, 0, 1, 2, 64>(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc, upper_only);
-	else if(t128 >= 192 && cfg == 2)
-		launch_gemm<128, 128, 32, 64, 0>(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc, upper_only);
-	else if(t128 >= 192 && cfg == 3)
-		launch_gemm<128, 64, 64, 32, 0>(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc, upper_only);
-	else if(t128 >= 192)
-		launch_gemm<128, 128, 64, 64, 0>(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc, upper_only);
-	else
+	bool big = false;
+	if(upper_only && t128 >= 50 && launch_gemm_mixed(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc))
+		big = true;
+	else if(t128 >= 192) {
+		launch_gemm<128, 128, 32, 32, 0, 1, 1>(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc, upper_only);
+		big = true;
+	} else
 		launch_gemm<64, 64, 32, 32, 0>(ctx->stream, m, n, (int)k, A, lda, B, ldb, C, ldc, upper_only);
 	SPP_HIP_CHECK(hipGetLastError());
-	return t128 >= 192 && (cfg == 9 || cfg >= 12); // true: a 16-wave 128 x 128-tile kernel (the one the roofline is reported for) was launched
+	return big; // true: a 16-wave 128 x 128-tile kernel (the one the roofline is reported for) was launched
 }
 
 __global__ __launch_bounds__(POTRF_THREADS)
@@ -785,11 +718,6 @@ static void ensure_dense_work(spp_ctx *ctx, int64_t nblk)
 	}
 	ctx->dense.xtmp.reserve((size_t)(nblk + 1) * NB);
 	if(!ctx->dense.aux) {
-		// the bulk update runs at the LOWEST priority: workgroups of the serial chain (on ctx->stream)
-		// are dispatched first whenever a CU frees up under a running trailing update
-		int prio_lo = 0, prio_hi = 0;
-		SPP_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-		const char *e = getenv("SPP_AUX_PRIO");
 		// The bulk stream is created with a CU mask that leaves the first n CUs (SPP_AUX_RESERVE_CUS, default 32)
 		// to the chain: under a running bulk update every wave slot of the chip is taken, potrf_diag and the
 		// tile-row workgroups otherwise wait for bulk workgroups to retire (measured: potrf_diag 33 -> 50..100 us,
@@ -808,14 +736,13 @@ static void ensure_dense_work(spp_ctx *ctx, int64_t nblk)
 				ctx->dense.aux = nullptr;
 			}
 		}
-		if(!ctx->dense.aux)
-		SPP_HIP_CHECK(hipStreamCreateWithPriority(&ctx->dense.aux, hipStreamNonBlocking,
-			(e && !strcmp(e, "hi")) ? prio_hi : prio_lo));
-		// third stream (tile-row remainder, see dense_factor_steps_enqueue). Not CU-masked: with a mask of "every CU
-		// but two" on it the factorization took twice as long (cause not established).
-		if(!ctx->dense.row)
-			SPP_HIP_CHECK(hipStreamCreateWithFlags(&ctx->dense.row, hipStreamNonBlocking));
-		SPP_HIP_CHECK(hipEventCreateWithFlags(&ctx->dense.ev_row, hipEventDisableTiming));
+		if(!ctx->dense.aux) {
+			// without a mask: at least the LOWEST priority, so that workgroups of the serial chain (on ctx->stream) are
+			// dispatched first whenever a CU frees up under a running trailing update
+			int prio_lo = 0, prio_hi = 0;
+			SPP_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+			SPP_HIP_CHECK(hipStreamCreateWithPriority(&ctx->dense.aux, hipStreamNonBlocking, prio_lo));
+		}
 		SPP_HIP_CHECK(hipEventCreateWithFlags(&ctx->dense.ev[0], hipEventDisableTiming));
 		SPP_HIP_CHECK(hipEventCreateWithFlags(&ctx->dense.ev[1], hipEventDisableTiming));
 	}
@@ -1099,6 +1026,14 @@ static bool flag_schedule_usable(spp_ctx *ctx)
 	return dw.sync_state == 1;
 }
 
+// The two-stream schedule. Chain (ctx stream): fused [tile row k+1 <- panel k, potrf_diag(k+1)], panel solve k+1.
+// Bulk (CU-masked second stream): everything below the tile row, handed over right after the panel solve; once the
+// trailing matrix is at most 2560 rows the whole step runs on the chain stream (one fused launch updates every
+// trailing tile and factors the next diagonal block as soon as ITS tile is done).
+// Measured in rounds 1-2 and no longer selectable (DESIGN.md section 3 records the numbers): handing the bulk update
+// over after the tile row, waiting for it under the running potrf_diag, a slab-pipelined tile-row / panel kernel,
+// pairs of steps as rank-256 updates, the rest of the tile row on a third stream beside potrf_diag, 64 x 64 and 64 x 32
+// tiles for the single-stream update, skipping the zero half of the block inverse in the panel solve.
 static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, int64_t n, int64_t rows, int64_t ncols,
 	int64_t nsteps, bool has_rhs, bool use_flags, bool allow_fused)
 {
@@ -1107,8 +1042,8 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 	// Hand-offs between the chain stream and the bulk stream: events (two barrier packets per direction, ~6 us
 	// each on the critical chain) or, with use_flags, words in device memory: flag[2 k] = "row panel k is
 	// complete" (signal kernel behind the panel solve on s, wait kernel in front of the bulk update on s2),
-	// flag[2 k + 1] = "bulk update k is complete" (signal kernel behind it on s2; the tile-row kernel of the
-	// chain polls it in its own prologue). Values are the epoch of this factorization.
+	// flag[2 k + 1] = "bulk update k is complete" (signal kernel behind it on s2; a wait kernel in front of the chain's
+	// next tile-row kernel). Values are the epoch of this factorization.
 	DenseWork &dw = ctx->dense;
 	// pivots [n_id, n) are exact identity padding (big fronts of the sparse path pad their pivot block to a multiple of
 	// 128): the diagonal-block kernel skips the 16-wide panels that consist of padding only
@@ -1123,8 +1058,7 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 			dw.sync_epoch = 1; // the self-test used the value 1
 		}
 		ep = ++ dw.sync_epoch;
-		// the bulk stream must not see flags of this epoch... it cannot: they are set by kernels enqueued below.
-		// It must start after everything enqueued on the ctx stream so far (the matrix itself): one event per factorization
+		// the bulk stream must start after everything enqueued on the ctx stream so far (the matrix itself): one event per factorization
 		SPP_HIP_CHECK(hipEventRecord(evA, s));
 		SPP_HIP_CHECK(hipStreamWaitEvent(s2, evA, 0));
 	}
@@ -1149,17 +1083,17 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 		else
 			SPP_HIP_CHECK(hipEventRecord(evB, s2));
 	};
-	auto wait_b_kernel = [&](hipStream_t st) { // a wait of its own (event or one-wave kernel)
-		if(use_flags && st == s && pend_sig >= 0) { // a deferred panel signal goes first (never left behind a wait)
+	auto wait_b_now = [&]() { // a wait of its own on the chain stream (event or one-wave kernel)
+		if(use_flags && pend_sig >= 0) { // a deferred panel signal goes first (never left behind a wait)
 			flag_signal(s, dw.sync.p + 2 * pend_sig, ep);
 			pend_sig = -1;
 		}
 		if(use_flags)
-			flag_wait(ctx, st, dw.sync.p + 2 * step_b + 1, ep);
+			flag_wait(ctx, s, dw.sync.p + 2 * step_b + 1, ep);
 		else
-			SPP_HIP_CHECK(hipStreamWaitEvent(st, evB, 0));
+			SPP_HIP_CHECK(hipStreamWaitEvent(s, evB, 0));
 	};
-	auto wait_b_deferred = [&]() { // the chain's next tile-row kernel waits in its prologue (flags), or an event wait now
+	auto wait_b_deferred = [&]() { // in front of the chain's next tile-row kernel (flags), or an event wait now
 		if(use_flags)
 			need_wait_b = step_b;
 		else
@@ -1175,28 +1109,7 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 			flag_signal(s, dw.sync.p + 2 * pend_sig, ep);
 		need_wait_b = pend_sig = -1;
 	};
-	static int64_t trsm_shared_above = -1;
-	if(trsm_shared_above < 0) {
-		const char *e = getenv("SPP_TRSM_SHARED_ABOVE");
-		trsm_shared_above = e ? atol(e) : (int64_t(1) << 40);
-	}
 	bool bulk_pending = false;
-	static int64_t wait_mid_below = -1;
-	if(wait_mid_below < 0) {
-		// SPP_WAIT_MID_BELOW: trailing rows below which the chain waits for the bulk update between potrf_diag
-		// and the panel solve of the NEXT step (the barrier packet is then processed under the running
-		// potrf_diag) instead of right before the tile row
-		const char *e = getenv("SPP_WAIT_MID_BELOW");
-		wait_mid_below = e ? atol(e) : 0;
-	}
-	static int panel_waves = -1, panel_tri = 0;
-	if(panel_waves < 0) {
-		const char *e = getenv("SPP_PANEL_WAVES"); // 4: two MFMA tiles per wave, 8: one
-		panel_waves = e ? atoi(e) : 8;
-		e = getenv("SPP_PANEL_TRI"); // skip the zero half of the triangular inverse: measured 1.5 % SLOWER (conditional loads, run-time loop bound)
-		panel_tri = e ? atoi(e) : 0;
-	}
-	bool row_pending = false; // the remainder of tile row k (stream ctx->dense.row) has to finish before panel k
 	// Fused chain kernel (update_potrf_kernel): the update of a row region from panel kp and the factorization of the
 	// region's first diagonal block (step kn) in one launch; the panel solve of step kn follows as its own launch.
 	static int fused_env = -1;
@@ -1243,131 +1156,43 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 			dw.fuse_cnt.p + slot, dw.info.p + 2, (long long)(500.0 * 1e5));
 		return true;
 	};
-	auto potrf_and_panel = [&](hipStream_t st, int64_t k, bool potrf_done = false) {
+	auto potrf_and_panel = [&](int64_t k, bool potrf_done = false) {
 		const int64_t k0 = k * NB;
 		const int n_valid = (int)std::max<int64_t>(0, std::min<int64_t>(NB, n_id - k0));
 		double *tinv = ctx->dense.tinv_all.p + (size_t)k * NB * NB;
 		if(!potrf_done)
-		hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(POTRF_THREADS), POTRF_LDS_DOUBLES * sizeof(double), st,
-			d_A + k0 + k0 * ld, ld, n_valid, (has_rhs && n_valid < NB) ? 1 : 0, tinv, ctx->dense.info.p, k0);
-		if(row_pending) {
-			SPP_HIP_CHECK(hipStreamWaitEvent(st, ctx->dense.ev_row, 0));
-			row_pending = false;
-		}
+			hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(POTRF_THREADS), POTRF_LDS_DOUBLES * sizeof(double), s,
+				d_A + k0 + k0 * ld, ld, n_valid, (has_rhs && n_valid < NB) ? 1 : 0, tinv, ctx->dense.info.p, k0);
 		const int64_t c1 = k0 + NB;
-		if(bulk_pending && rows - c1 < wait_mid_below) {
-			wait_b_kernel(st);
-			bulk_pending = false;
-		}
-		if(c1 < ncols) { // panel: R_kj = Tinv^T S_kj in place (A = tinv: 128 x 128; B = C = S[k0.., c1..])
-			// While the bulk update of the previous step fills the chip (large trailing matrix) the fully
-			// staged kernel -- 150 KB of LDS per workgroup -- only gets CUs as they drain completely and
-			// finishes with the bulk update, delaying the next one. The slab-pipelined kernel (23 KB, 4
-			// waves) shares CUs with the update's workgroups. The staged one has the lower latency when
-			// the chain is what bounds the step (small trailing matrix).
-			if(ncols - c1 >= trsm_shared_above)
-				launch_gemm<128, 32, 32, 32, 1>(st, NB, ncols - c1, NB, tinv, NB, d_A + k0 + c1 * ld, ld,
-					d_A + k0 + c1 * ld, ld, false);
-			else
-				if(panel_waves == 8 && panel_tri) // one MFMA tile per wave; the inverse is upper triangular: half of it is neither fetched nor multiplied
-					launch_gemm_staged<128, 16, 16, 16, 1, 1>(st, NB, ncols - c1, NB, tinv, NB, d_A + k0 + c1 * ld, ld,
-						d_A + k0 + c1 * ld, ld, false);
-				else if(panel_waves == 8)
-					launch_gemm_staged<128, 16, 16, 16, 1>(st, NB, ncols - c1, NB, tinv, NB, d_A + k0 + c1 * ld, ld,
-						d_A + k0 + c1 * ld, ld, false);
-				else
-				launch_gemm_staged<128, 16, 32, 16, 1>(st, NB, ncols - c1, NB, tinv, NB, d_A + k0 + c1 * ld, ld,
-					d_A + k0 + c1 * ld, ld, false);
-		}
+		if(c1 < ncols) // panel: R_kj = Tinv^T S_kj in place (A = tinv: 128 x 128; B = C = S[k0.., c1..]); one MFMA tile per wave
+			launch_gemm_staged<128, 16, 16, 16, 1>(s, NB, ncols - c1, NB, tinv, NB, d_A + k0 + c1 * ld, ld,
+				d_A + k0 + c1 * ld, ld, false);
 	};
-	// Steps are processed in PAIRS: the bulk update applies two row panels at once (K = 256), which
-	// halves the read-modify-write traffic of the trailing matrix per flop (the K = 128 update sits on
-	// the HBM ridge: 8 flop/B). Within a pair the chain stream does
-	//   tile row k+1 <- panel k | potrf(k+1), panel k+1 | tile row k+2 <- panels k, k+1
-	// and the bulk stream updates everything below tile row k+2 with both panels.
-	static int tilerow_tile = -1;
-	static int64_t tilerow_slab_above = 0;
-	if(tilerow_tile < 0) {
-		const char *e = getenv("SPP_TILEROW_TILE");
-		tilerow_tile = e ? atoi(e) : 32;
-		e = getenv("SPP_TILEROW_SLAB_ABOVE");
-		tilerow_slab_above = e ? atol(e) : (int64_t(1) << 40);
-	}
-	auto tile_row = [&](int64_t r0, int64_t kp0, int npan) { // rows [r0, r0+128) x cols [r0, ncols) -= P^T P, panels at kp0
+	auto tile_row = [&](int64_t r0, int64_t kp0) { // rows [r0, r0 + 128) x cols [r0, ncols) -= P^T P, panel at kp0
 		const int64_t m = std::min<int64_t>(NB, rows - r0);
 		if(m <= 0 || r0 >= ncols)
 			return;
-		for(int q = 0; q < npan; ++ q) {
-			const double *P = d_A + (kp0 + q * NB) + r0 * ld;
-			flush_wait_b();
-			// Under a running bulk update every wave slot of the chip is taken and a tile-row workgroup only
-			// starts where a bulk workgroup has just left: the fully staged kernel (66 KB of LDS) fits once
-			// into such a hole, the slab-pipelined one (18 KB, one wave per SIMD) four times.
-			if(rows - r0 > tilerow_slab_above)
-				launch_gemm<64, 64, 32, 32, 0, 1>(s, m, ncols - r0, NB, P, ld, P, ld, d_A + r0 + r0 * ld, ld, true);
-			else if(tilerow_tile == 32)
-				launch_gemm_staged<32, 32, 16, 16, 0>(s, m, ncols - r0, NB, P, ld, P, ld, d_A + r0 + r0 * ld, ld, true);
-			else
-				launch_gemm_staged<64, 64, 32, 32, 0>(s, m, ncols - r0, NB, P, ld, P, ld, d_A + r0 + r0 * ld, ld, true);
-		}
+		const double *P = d_A + kp0 + r0 * ld;
+		flush_wait_b();
+		launch_gemm_staged<32, 32, 16, 16, 0>(s, m, ncols - r0, NB, P, ld, P, ld, d_A + r0 + r0 * ld, ld, true);
 	};
-	potrf_and_panel(s, 0);
-	// pairing pays once the bulk update is shorter than the serial chain (it then hides anyway and the
-	// pair saves one cross-stream hand-off); while the trailing matrix is large the single-step schedule
-	// overlaps better. SPP_PAIR_BELOW = trailing rows below which steps are paired.
-	static int64_t pair_below = -1, pair_above = -1;
-	if(pair_below < 0) {
-		const char *e = getenv("SPP_PAIR_BELOW");
-		pair_below = e ? atol(e) : 0; // measured on Venice-871: pairing raises the update kernel's TFLOP/s but never the wall time
-		e = getenv("SPP_PAIR_ABOVE");
-		pair_above = e ? atol(e) : (int64_t(1) << 40); // pair while the trailing matrix is LARGER than this (bulk-bound phase)
-	}
-	static int eva_early = -1, split_row = 0;
-	static int64_t early_above = 0;
-	if(eva_early < 0) {
-		const char *e = getenv("SPP_EVA_EARLY");
-		eva_early = e ? atoi(e) : 1;
-		e = getenv("SPP_EARLY_ABOVE"); // the bulk update is handed over before the tile row only while it bounds the step
-		early_above = e ? atol(e) : 0;
-		e = getenv("SPP_SPLIT_TILEROW"); // measured: no gain (the extra cross-stream events cost what the overlap saves)
-		split_row = e ? atoi(e) : 0;
-	}
-	// Once the trailing matrix is small the whole update is shorter than a cross-stream hand-off plus the
-	// tile row (two events cost ~12 us per step): the step then runs on the chain stream alone,
-	//   potrf(k), panel(k), ONE launch updating every trailing tile, potrf(k+1) ...
-	// SPP_SINGLE_BELOW = trailing rows at or below which a step is single-stream.
-	static int64_t single_below = -1;
-	static int single_tile = 64;
-	static int64_t single_mixed_above = 1280;
-	static int64_t fused_below = -1;
-	if(fused_below < 0) {
-		const char *e = getenv("SPP_FUSED_BELOW"); // single-stream steps with at most this many trailing rows use the fused kernel
-		fused_below = e ? atol(e) : (int64_t(1) << 40);
-	}
-	if(single_below < 0) {
-		const char *e = getenv("SPP_SINGLE_BELOW");
-		single_below = e ? atol(e) : 2560;
-		e = getenv("SPP_SINGLE_TILE");
-		single_tile = e ? atoi(e) : 32;
-		e = getenv("SPP_SINGLE_MIXED_ABOVE");
-		single_mixed_above = e ? atol(e) : 1280;
-	}
-	for(int64_t k = 0; k < nsteps;) {
-		const int64_t k0 = k * NB, c1 = k0 + NB, c2 = c1 + NB, c3 = c2 + NB;
-		const int npan = ((rows - c1 < pair_below || rows - c1 > pair_above) && k + 1 < nsteps) ? 2 : 1;
+	potrf_and_panel(0);
+	const int64_t single_below = 2560, single_mixed_above = 1280;
+	for(int64_t k = 0; k < nsteps; ++ k) {
+		const int64_t k0 = k * NB, c1 = k0 + NB, c2 = c1 + NB;
 		if(c1 >= ncols || rows - c1 <= 0)
 			break;
 		if(rows - c1 <= single_below) {
+			// small trailing matrix: the whole update is shorter than a cross-stream hand-off plus the tile row
 			if(bulk_pending) {
-				wait_b_kernel(s);
+				wait_b_now();
 				bulk_pending = false;
 			}
 			const double *P = d_A + k0 + c1 * ld;
-			if(fused && rows - c1 <= fused_below && k + 1 < nsteps && rows - c1 >= NB) {
+			if(fused && k + 1 < nsteps && rows - c1 >= NB) {
 				// one launch: every trailing tile <- panel k, the next diagonal block factored as soon as ITS tile is done
 				fused_update_potrf(c1, rows - c1, k0, k + 1);
-				potrf_and_panel(s, k + 1, true);
-				++ k;
+				potrf_and_panel(k + 1, true);
 				continue;
 			}
 			if(rows - c1 >= single_mixed_above) { // the fine-grained MFMA kernel wins from ~10 tile rows on
@@ -1376,96 +1201,53 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 				const double mr = (double)(rows - c1);
 				if(big)
 					dom_end(ctx, 2.0 * NB * (0.5 * mr * (mr + 1.0) + mr * (double)(ncols - rows)));
-			} else if(single_tile == 32)
+			} else
 				launch_gemm_staged<32, 32, 16, 16, 0>(s, rows - c1, ncols - c1, NB, P, ld, P, ld, d_A + c1 + c1 * ld, ld, true);
-			else if(single_tile == 48)
-				launch_gemm_staged<64, 32, 32, 16, 0>(s, rows - c1, ncols - c1, NB, P, ld, P, ld, d_A + c1 + c1 * ld, ld, true);
-			else
-				launch_gemm_staged<64, 64, 32, 32, 0>(s, rows - c1, ncols - c1, NB, P, ld, P, ld, d_A + c1 + c1 * ld, ld, true);
 			if(k + 1 < nsteps)
-				potrf_and_panel(s, k + 1);
-			++ k;
+				potrf_and_panel(k + 1);
 			continue;
 		}
-		// A single-panel bulk update needs only row panel k (complete at this point of the chain stream)
-		// and writes rows >= c2, disjoint from the tile row the chain touches next: hand it to the bulk
-		// stream BEFORE the tile row, so that consecutive bulk updates run back to back.
-		const bool early = (npan == 1) && eva_early && rows - c1 > early_above;
-		if(early)
-			record_a(k);
-		// the bulk update of the previous pair touched every row >= c1 (evB still names that update:
-		// this wait is issued before the next record)
-		if(bulk_pending) {
+		// The bulk update needs only row panel k (complete at this point of the chain stream) and writes rows >= c2,
+		// disjoint from the tile row the chain touches next: it is handed to the bulk stream BEFORE the tile row, so
+		// that consecutive bulk updates run back to back.
+		record_a(k);
+		if(bulk_pending) { // the previous bulk update touched every row >= c1
 			wait_b_deferred();
-			if(early && split_row) // the third stream updates row k+1 as well; evB is re-recorded below
-				wait_b_kernel(ctx->dense.row);
 			bulk_pending = false;
 		}
-		const int64_t cb = (npan == 2) ? c3 : c2;
-		const bool have_bulk = rows - cb > 0 && cb < ncols;
+		const bool have_bulk = rows - c2 > 0 && c2 < ncols;
 		bool fused_done = false; // potrf of step k+1 already done by the fused kernel
-		if(!early || !have_bulk) {
-			tile_row(c1, k0, 1);
-			flush_wait_b();
-			if(npan == 2) {
-				potrf_and_panel(s, k + 1);
-				tile_row(c2, k0, 2);
-			}
-		}
-		// bulk: rows [cb, rows) x cols [cb, ncols) -= P^T P with P = rows [k0, k0 + 128 npan)
 		if(have_bulk) {
-			if(!early)
-				record_a(k); // both panels (and the tile rows) are complete here
 			wait_a_on_bulk();
-			const double *P = d_A + k0 + cb * ld;
+			const double *P = d_A + k0 + c2 * ld;
 			hipStream_t keep = ctx->stream;
 			ctx->stream = s2; // dom events + gemm launch on the bulk stream
 			dom_begin(ctx);
-			const bool big = dense_gemm_tn_sub(ctx, rows - cb, ncols - cb, NB * npan, P, ld, P, ld, d_A + cb + cb * ld, ld, true);
-			const double mr = (double)(rows - cb);
+			const bool big = dense_gemm_tn_sub(ctx, rows - c2, ncols - c2, NB, P, ld, P, ld, d_A + c2 + c2 * ld, ld, true);
+			const double mr = (double)(rows - c2);
 			// useful flops: upper triangle of the M x M part + the (N - M) extra columns (rhs); only the
 			// launches of the 128 x 128-tile kernel are accounted (one kernel symbol = one rocprof row)
 			if(big)
-				dom_end(ctx, 2.0 * NB * npan * (0.5 * mr * (mr + 1.0) + mr * (double)(ncols - rows)));
+				dom_end(ctx, 2.0 * NB * (0.5 * mr * (mr + 1.0) + mr * (double)(ncols - rows)));
 			ctx->stream = keep;
 			record_b(k);
 			bulk_pending = true;
-			if(early) {
-				const int64_t m = std::min<int64_t>(NB, rows - c1);
-				if(split_row && m == NB && ncols - c2 > 0) {
-					flush_wait_b();
-					// potrf_diag(k+1) needs the diagonal tile of row k+1 only; the rest of the row is needed by the
-					// panel solve AFTER it and is updated beside potrf_diag on the third stream
-					hipStream_t s3 = ctx->dense.row;
-					SPP_HIP_CHECK(hipStreamWaitEvent(s3, evA, 0)); // row panel k complete (bulk update k-1: waited for above)
-					const double *Pa = d_A + k0 + c1 * ld, *Pb = d_A + k0 + c2 * ld;
-					launch_gemm_staged<32, 32, 16, 16, 0>(s3, NB, ncols - c2, NB, Pa, ld, Pb, ld, d_A + c1 + c2 * ld, ld, false);
-					SPP_HIP_CHECK(hipEventRecord(ctx->dense.ev_row, s3));
-					row_pending = true;
-					launch_gemm_staged<32, 32, 16, 16, 0>(s, NB, NB, NB, Pa, ld, Pa, ld, d_A + c1 + c1 * ld, ld, true);
-				} else if(fused && npan == 1 && k + 1 < nsteps && rows - c1 >= NB) {
-					flush_wait_b();
-					fused_update_potrf(c1, NB, k0, k + 1); // tile row k+1 <- panel k, potrf(k+1) inside
-					fused_done = true;
-				} else
-					tile_row(c1, k0, 1);
-			}
 		}
-		flush_wait_b();
-		// next pair's first diagonal block + row panel overlaps the bulk update
-		if(k + npan < nsteps)
-			potrf_and_panel(s, k + npan, fused_done);
-		k += npan;
-	}
-	if(bulk_pending) {
-		if(use_flags) { // the join is an event: the ctx stream's successors need the whole bulk stream drained
-			SPP_HIP_CHECK(hipEventRecord(evB, s2));
-			SPP_HIP_CHECK(hipStreamWaitEvent(s, evB, 0));
+		if(fused && k + 1 < nsteps && rows - c1 >= NB) {
+			flush_wait_b();
+			fused_update_potrf(c1, NB, k0, k + 1); // tile row k+1 <- panel k, potrf(k+1) inside
+			fused_done = true;
 		} else
-			SPP_HIP_CHECK(hipStreamWaitEvent(s, evB, 0));
+			tile_row(c1, k0);
+		flush_wait_b();
+		if(k + 1 < nsteps)
+			potrf_and_panel(k + 1, fused_done);
 	}
-	if(row_pending)
-		SPP_HIP_CHECK(hipStreamWaitEvent(s, ctx->dense.ev_row, 0));
+	if(bulk_pending) { // the join is an event: the ctx stream's successors need the whole bulk stream drained
+		if(use_flags)
+			SPP_HIP_CHECK(hipEventRecord(evB, s2));
+		SPP_HIP_CHECK(hipStreamWaitEvent(s, evB, 0));
+	}
 	SPP_HIP_CHECK(hipGetLastError());
 }
 

@@ -6,17 +6,12 @@
 #include "spp_internal.h"
 #include "spp_tiles.h"
 
-// The fp64 MFMA form used by the tile products. Measured on MI355X (tools/mfma_rate.hip, tools/mfma444_layout.hip):
-//   v_mfma_f64_16x16x4     2048 flop, one per ~101 cycles and SIMD (8 waves, 4 accumulators each)  -> 48 TFLOP/s
-//   v_mfma_f64_4x4x4_4b     512 flop, one per ~18 cycles and SIMD, 52 cycles dependent latency      -> 72 TFLOP/s
-// Lane maps of the 4x4x4_4b form (four independent blocks blk = (lane >> 2) & 3):
-//   A[blk][i][k] in lane 16 k + 4 blk + i,  B[blk][k][j] in lane 16 k + 4 blk + j,  D[blk][i][j] in lane 16 i + 4 blk + j.
-// With the same A replicated in all four blocks the instruction is a (4 x 4) . (4 x 16) product whose B operand and
-// result rows are laid out exactly like the 16x16x4 form's (k resp. row = lane >> 4, column = lane & 15): strip r of a
-// 16 x 16 tile is accumulator register r of the old form, only the A operand is fetched per strip.
-#ifndef SPP_MFMA_444
-#define SPP_MFMA_444 0 // measured in the LDS-fed tile products: 20-30 TFLOP/s against 41 with the 16x16x4 form
-#endif
+// The fp64 MFMA form used by the tile products is v_mfma_f64_16x16x4 (2048 flop). Measured on MI355X with the operand
+// pattern of a real tile product (tools/mfma_rate2.hip: a register outer product, distinct operand registers per
+// instruction) it issues once per ~75 cycles and SIMD = 67 TFLOP/s chip-wide; v_mfma_f64_4x4x4_4b (four independent
+// 4 x 4 x 4 blocks, 512 flop; lane maps: A[blk][i][k] in lane 16 k + 4 blk + i, B[blk][k][j] in lane 16 k + 4 blk + j,
+// D[blk][i][j] in lane 16 i + 4 blk + j) once per 16-17 cycles = 77 TFLOP/s -- 14 % apart, at four times the operand
+// words per flop. The tile built around the small form (spp_dense_444.h) measures slower; it is kept there, selectable.
 
 namespace spp {
 
@@ -102,25 +97,6 @@ __device__ __forceinline__ void gemm_tn_staged_tile(const int64_t m0, const int6
 	const int kend = (a_upper_tri && wm + WM < FS_KMAX) ? wm + WM : FS_KMAX; // compile-time FS_KMAX unless ATRI
 #pragma unroll 4
 	for(int k4 = 0; k4 < kend; k4 += 4) {
-#if SPP_MFMA_444
-		// four v_mfma_f64_4x4x4_4b per 16 x 16 tile and k-step instead of one v_mfma_f64_16x16x4 (see the note at the top)
-		double fa[TA], fb[TB][4];
-#pragma unroll
-		for(int a = 0; a < TA; ++ a)
-			fa[a] = As[(wm + a * 16 + l15) * FS_STRIDE + k4 + l4];
-#pragma unroll
-		for(int b = 0; b < TB; ++ b)
-#pragma unroll
-			for(int r = 0; r < 4; ++ r)
-				fb[b][r] = Bs[(wn + b * 16 + 4 * r + (lane & 3)) * FS_STRIDE + k4 + l4];
-#pragma unroll
-		for(int b = 0; b < TB; ++ b)
-#pragma unroll
-			for(int a = 0; a < TA; ++ a)
-#pragma unroll
-				for(int r = 0; r < 4; ++ r)
-					acc[b][a][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(fb[b][r], fa[a], acc[b][a][r], 0, 0, 0);
-#else
 		double fa[TA], fb[TB];
 #pragma unroll
 		for(int a = 0; a < TA; ++ a)
@@ -133,7 +109,6 @@ __device__ __forceinline__ void gemm_tn_staged_tile(const int64_t m0, const int6
 #pragma unroll
 			for(int a = 0; a < TA; ++ a)
 				acc[b][a] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[b], fa[a], acc[b][a], 0, 0, 0);
-#endif
 	}
 #pragma unroll
 	for(int b = 0; b < TB; ++ b)

@@ -236,8 +236,6 @@ struct DenseWork {
 	int *h_chain_err = nullptr;
 	hipStream_t aux = nullptr;     // lookahead stream: potrf_diag + trsm of the next panel
 	hipEvent_t ev[2] = {nullptr, nullptr};
-	hipStream_t row = nullptr;     // third stream: the part of tile row k+1 that only the NEXT panel solve needs
-	hipEvent_t ev_row = nullptr;
 	// device-flag hand-offs between the chain stream and the bulk stream (dense_factor_steps_enqueue):
 	// sync[2 k] = row panel k complete, sync[2 k + 1] = bulk update k complete, as the epoch of the factorization
 	DevBuf<int> sync;

@@ -55,33 +55,17 @@ __device__ __forceinline__ double and_f64(double v, int word)
 
 // D (16 x 16) = sum_k A[k][i] * B[k][j], k = 0..15; A element (k, i) at a[k * aks + i * ais],
 // B element (k, j) at b[k * bks + j * bjs]. Result in the MFMA D layout (row (l>>4) + 4 r, col l & 15).
-#ifndef SPP_MFMA_444_TILES
-#define SPP_MFMA_444_TILES 0 // 1: the 16 x 16 tile products as four v_mfma_f64_4x4x4_4b strips per k-step (52 cycles of dependent latency each)
-#endif
 
 __device__ __forceinline__ v4f64 tile_atb(const double *a, int aks, int ais, const double *b, int bks, int bjs, int lane)
 {
 	v4f64 acc = (v4f64){0, 0, 0, 0};
 	const int l15 = lane & 15, l4 = lane >> 4;
-#if SPP_MFMA_444_TILES
-	const int l3 = lane & 3;
-#pragma unroll
-	for(int kk = 0; kk < 4; ++ kk) {
-		const double fb = b[(kk * 4 + l4) * bks + l15 * bjs];
-#pragma unroll
-		for(int r = 0; r < 4; ++ r) {
-			const double fa = a[(kk * 4 + l4) * aks + (4 * r + l3) * ais]; // rows 4 r .. 4 r + 3, replicated over the four blocks
-			acc[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa, fb, acc[r], 0, 0, 0);
-		}
-	}
-#else
 #pragma unroll
 	for(int kk = 0; kk < 4; ++ kk) {
 		const double fa = a[(kk * 4 + l4) * aks + l15 * ais];
 		const double fb = b[(kk * 4 + l4) * bks + l15 * bjs];
 		acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, fb, acc, 0, 0, 0);
 	}
-#endif
 	return acc;
 }
 
@@ -92,19 +76,6 @@ __device__ __forceinline__ void tile_atb2_rt(const int TS, const double *a0, con
 	d0 = (v4f64){0, 0, 0, 0};
 	d1 = (v4f64){0, 0, 0, 0};
 	const int l15 = lane & 15, l4 = lane >> 4;
-#if SPP_MFMA_444_TILES
-	const int l3 = lane & 3;
-#pragma unroll
-	for(int kk = 0; kk < 4; ++ kk) {
-		const double fb0 = b0[(kk * 4 + l4) * b0ks + l15 * b0js];
-		const double fb1 = b1[(kk * 4 + l4) * b1ks + l15 * b1js];
-#pragma unroll
-		for(int r = 0; r < 4; ++ r) {
-			d0[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a0[(kk * 4 + l4) + (4 * r + l3) * TS], fb0, d0[r], 0, 0, 0);
-			d1[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[(kk * 4 + l4) + (4 * r + l3) * TS], fb1, d1[r], 0, 0, 0);
-		}
-	}
-#else
 	double fa0[4], fb0[4], fa1[4], fb1[4];
 #pragma unroll
 	for(int kk = 0; kk < 4; ++ kk) {
@@ -118,7 +89,6 @@ __device__ __forceinline__ void tile_atb2_rt(const int TS, const double *a0, con
 		d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa0[kk], fb0[kk], d0, 0, 0, 0);
 		d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa1[kk], fb1[kk], d1, 0, 0, 0);
 	}
-#endif
 }
 
 // three independent tiles at once (operand element (k, i) of a tile at a[k + i * TS], (k, j) at b[k + j * bjs])
