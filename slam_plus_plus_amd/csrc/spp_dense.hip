@@ -428,7 +428,71 @@ void potrf_diag_kernel(double *__restrict__ Ablk, int64_t ld, int n_valid, int h
 	double *__restrict__ tinv, int *__restrict__ info, int64_t k0)
 {
 	extern __shared__ double sm[];
-	potrf_diag_body<false>(Ablk, ld, n_valid, has_rhs, tinv, info, k0, sm);
+	potrf_diag_body<false, 0, 1>(Ablk, ld, n_valid, has_rhs, tinv, info, k0, sm);
+}
+
+// row panel of a step: R_kj = R_kk^-T S_kj in place, one 16-column slab per workgroup (panel_solve_slab: the diagonal
+// block's inverse in the two-halves form potrf_diag_body<.., .., 1> stores)
+constexpr int PANEL_THREADS = 512;
+__global__ __launch_bounds__(PANEL_THREADS)
+void panel_solve_kernel(int64_t N, const double *__restrict__ tinv, double *Y, int64_t ld)
+{
+	extern __shared__ double fs_lds[];
+	panel_solve_slab<PANEL_THREADS>((int64_t)blockIdx.x * 16, N, tinv, Y, ld, fs_lds);
+}
+
+static void launch_panel_solve(hipStream_t s, int64_t N, const double *tinv, double *Y, int64_t ld)
+{
+	static uint64_t attr_seen = 0;
+	const size_t lds = (size_t)(NB + 16) * FS_STRIDE * sizeof(double);
+	if(first_on_this_device(attr_seen))
+		SPP_HIP_CHECK(hipFuncSetAttribute((const void*)panel_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	if(N <= 0)
+		return;
+	hipLaunchKernelGGL(panel_solve_kernel, dim3((unsigned)((N + 15) / 16)), dim3(PANEL_THREADS), lds, s, N, tinv, Y, ld);
+}
+
+// The two-halves form [T0 R01; 0 T1] of every stored diagonal-block inverse becomes the full inverse
+// [T0  -T0 R01 T1; 0  T1] in place -- once per factorization, off its critical chain, for the backward substitution
+// (which multiplies by whole block inverses). One workgroup per block, one 16 x 16 tile of the 64 x 64 block per wave.
+constexpr int TF_STRIDE = 66;
+__global__ __launch_bounds__(1024)
+void tinv_finish_kernel(double *__restrict__ tinv_all)
+{
+	__shared__ double T0[64 * TF_STRIDE], R01[64 * TF_STRIDE], T1[64 * TF_STRIDE], Nm[64 * TF_STRIDE];
+	double *tv = tinv_all + (size_t)blockIdx.x * NB * NB;
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+	for(int e = tid; e < 64 * 64; e += 1024) {
+		const int r = e & 63, c = e >> 6;
+		T0[r + c * TF_STRIDE] = tv[r + (size_t)c * NB];
+		R01[r + c * TF_STRIDE] = tv[r + (size_t)(64 + c) * NB];
+		T1[r + c * TF_STRIDE] = tv[64 + r + (size_t)(64 + c) * NB];
+	}
+	__syncthreads();
+	const int it = wave & 3, jt = wave >> 2; // tile (it, jt) of the 64 x 64 block
+	{
+		// N = R01 T1 (T1 upper triangular: k tiles 0 .. jt)
+		v4f64 acc = (v4f64){0, 0, 0, 0};
+		for(int kt = 0; kt <= jt; ++ kt) {
+			const v4f64 m = tile_atb(R01 + 16 * it + 16 * kt * TF_STRIDE, TF_STRIDE, 1, T1 + 16 * kt + 16 * jt * TF_STRIDE, 1, TF_STRIDE, lane);
+			acc += m;
+		}
+#pragma unroll
+		for(int r = 0; r < 4; ++ r)
+			Nm[16 * it + l4 + 4 * r + (16 * jt + l15) * TF_STRIDE] = acc[r];
+	}
+	__syncthreads();
+	{
+		// -T0 N (T0 upper triangular: k tiles it .. 3)
+		v4f64 acc = (v4f64){0, 0, 0, 0};
+		for(int kt = it; kt < 4; ++ kt) {
+			const v4f64 m = tile_atb(T0 + 16 * it + 16 * kt * TF_STRIDE, TF_STRIDE, 1, Nm + 16 * kt + 16 * jt * TF_STRIDE, 1, TF_STRIDE, lane);
+			acc += m;
+		}
+#pragma unroll
+		for(int r = 0; r < 4; ++ r)
+			tv[16 * it + l4 + 4 * r + (size_t)(64 + 16 * jt + l15) * NB] = -acc[r];
+	}
 }
 
 
@@ -503,7 +567,7 @@ void update_potrf_kernel(int64_t M, int64_t N, const double *P, int64_t ld, doub
 			return;
 		// (a fence-free variant -- write-through stores of the sub-tiles, sc1 loads here: potrf_diag_body<true> -- measured
 		// the same within noise; the release / acquire pair is the form kept)
-		potrf_diag_body<false>(C, ld, n_valid, has_rhs, tinv, info, k0_next, sm);
+		potrf_diag_body<false, 0, 1>(C, ld, n_valid, has_rhs, tinv, info, k0_next, sm);
 		return;
 	}
 	// the rest of the region in 64 x 64 blocks, block columns first
@@ -960,8 +1024,10 @@ void dense_factor_steps(spp_ctx *ctx, double *d_A, int64_t ld, int64_t n, int64_
 	const bool capturing = hipStreamIsCapturing(ctx->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
 	if(!capturing && la_usable(ctx, nsteps)) { // lookahead: persistent chain kernel + one bulk launch per step
 		dense_factor_lookahead(ctx, d_A, ld, n, rows, ncols, nsteps, has_rhs);
+		ctx->dense.tinv_half = 0; // (its chain stores whole inverses)
 		return;
 	}
+	ctx->dense.tinv_half = nsteps;
 	const bool flags = !capturing && nsteps >= 4 && flag_schedule_usable(ctx); // cross-stream hand-offs through device flags instead of events
 	dense_factor_steps_enqueue(ctx, d_A, ld, n, rows, ncols, nsteps, has_rhs, flags, !capturing);
 }
@@ -1070,20 +1136,35 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 		else
 			SPP_HIP_CHECK(hipEventRecord(evA, s));
 	};
+	// (flags) the bulk stream's "bulk update k is complete" is not enqueued on its own either: the wait for the next row
+	// panel follows it directly on that stream, and the two are one launch -- a one-wave kernel costs 5-6 us of queue time
+	// each, between two bulk updates that otherwise run back to back
+	int64_t pend_sig_b = -1;
 	auto wait_a_on_bulk = [&]() {
-		if(use_flags)
+		if(use_flags && pend_sig_b >= 0) {
+			hipLaunchKernelGGL(flag_signal_wait_kernel, dim3(1), dim3(64), 0, s2, dw.sync.p + 2 * pend_sig_b + 1, ep,
+				make_flag_wait(ctx, dw.sync.p + 2 * step_a, ep));
+			pend_sig_b = -1;
+		} else if(use_flags)
 			flag_wait(ctx, s2, dw.sync.p + 2 * step_a, ep);
 		else
 			SPP_HIP_CHECK(hipStreamWaitEvent(s2, evA, 0));
 	};
+	auto flush_sig_b = [&]() {
+		if(pend_sig_b >= 0)
+			flag_signal(s2, dw.sync.p + 2 * pend_sig_b + 1, ep);
+		pend_sig_b = -1;
+	};
 	auto record_b = [&](int64_t k) { // bulk update k is complete on s2
 		step_b = k;
 		if(use_flags)
-			flag_signal(s2, dw.sync.p + 2 * k + 1, ep);
+			pend_sig_b = k; // enqueued with the wait for row panel k + 1 (wait_a_on_bulk), or by flush_sig_b()
 		else
 			SPP_HIP_CHECK(hipEventRecord(evB, s2));
 	};
 	auto wait_b_now = [&]() { // a wait of its own on the chain stream (event or one-wave kernel)
+		if(use_flags && pend_sig_b == step_b)
+			flush_sig_b(); // (no further hand-over to the bulk stream took the signal along)
 		if(use_flags && pend_sig >= 0) { // a deferred panel signal goes first (never left behind a wait)
 			flag_signal(s, dw.sync.p + 2 * pend_sig, ep);
 			pend_sig = -1;
@@ -1100,6 +1181,8 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 			SPP_HIP_CHECK(hipStreamWaitEvent(s, evB, 0));
 	};
 	auto flush_wait_b = [&]() { // everything deferred on the chain stream: the panel signal, the wait for a bulk update, or both in one launch
+		if(need_wait_b >= 0 && pend_sig_b == need_wait_b)
+			flush_sig_b(); // the signal this wait is for must be in the bulk stream's queue
 		if(need_wait_b >= 0 && pend_sig >= 0)
 			hipLaunchKernelGGL(flag_signal_wait_kernel, dim3(1), dim3(64), 0, s, dw.sync.p + 2 * pend_sig, ep,
 				make_flag_wait(ctx, dw.sync.p + 2 * need_wait_b + 1, ep));
@@ -1164,9 +1247,8 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 			hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(POTRF_THREADS), POTRF_LDS_DOUBLES * sizeof(double), s,
 				d_A + k0 + k0 * ld, ld, n_valid, (has_rhs && n_valid < NB) ? 1 : 0, tinv, ctx->dense.info.p, k0);
 		const int64_t c1 = k0 + NB;
-		if(c1 < ncols) // panel: R_kj = Tinv^T S_kj in place (A = tinv: 128 x 128; B = C = S[k0.., c1..]); one MFMA tile per wave
-			launch_gemm_staged<128, 16, 16, 16, 1>(s, NB, ncols - c1, NB, tinv, NB, d_A + k0 + c1 * ld, ld,
-				d_A + k0 + c1 * ld, ld, false);
+		if(c1 < ncols) // panel: R_kj = R_kk^-T S_kj in place, 16-column slabs, one MFMA tile per wave
+			launch_panel_solve(s, ncols - c1, tinv, d_A + k0 + c1 * ld, ld);
 	};
 	auto tile_row = [&](int64_t r0, int64_t kp0) { // rows [r0, r0 + 128) x cols [r0, ncols) -= P^T P, panel at kp0
 		const int64_t m = std::min<int64_t>(NB, rows - r0);
@@ -1244,6 +1326,7 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 			potrf_and_panel(k + 1, fused_done);
 	}
 	if(bulk_pending) { // the join is an event: the ctx stream's successors need the whole bulk stream drained
+		pend_sig_b = -1; // (nobody waits for that flag)
 		if(use_flags)
 			SPP_HIP_CHECK(hipEventRecord(evB, s2));
 		SPP_HIP_CHECK(hipStreamWaitEvent(s, evB, 0));
@@ -1319,6 +1402,10 @@ void dense_potrs_upper(spp_ctx *ctx, const double *d_R, int64_t n, int64_t ld, d
 {
 	const int64_t nblk = (n + NB - 1) / NB;
 	hipStream_t s = ctx->stream;
+	if(ctx->dense.tinv_half > 0) { // the factorization left [T0 R01; 0 T1] per block: whole inverses from here on
+		hipLaunchKernelGGL(tinv_finish_kernel, dim3((unsigned)ctx->dense.tinv_half), dim3(1024), 0, s, ctx->dense.tinv_all.p);
+		ctx->dense.tinv_half = 0;
+	}
 	static int chain = -1;
 	if(chain < 0) {
 		const char *e = getenv("SPP_TRSV_CHAIN");

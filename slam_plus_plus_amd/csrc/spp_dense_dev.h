@@ -15,6 +15,13 @@
 
 namespace spp {
 
+// workgroup barrier that orders LDS accesses only (s_waitcnt lgkmcnt(0) + s_barrier): unlike __syncthreads()
+// it does not wait for outstanding global stores
+__device__ __forceinline__ void lds_barrier()
+{
+	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // Fully staged variant for the latency-critical chain kernels (row-panel solve and tile-row update):
 // K <= 128, both operand panels are loaded into LDS ONCE (all global loads in flight together, one
 // barrier), then the MFMAs run without further synchronization. LDS row stride K_MAX + 2 doubles:
@@ -129,6 +136,98 @@ __device__ __forceinline__ void gemm_tn_staged_tile(const int64_t m0, const int6
 		}
 }
 
+// Row-panel solve of one 16-column slab, X = R_kk^-T Y in place, with the diagonal block's inverse in the HALF form
+// potrf_diag_body<.., .., 1> leaves: tinv = [T0  R01; 0  T1] (T0, T1 the inverses of R_kk's two 64 x 64 diagonal
+// blocks, R01 its off-diagonal block):
+//     X0 = T0^T Y0 ;  W = Y1 - R01^T X0 ;  X1 = T1^T W
+// One 16 x 16 MFMA tile of X per wave (waves 0..3: X0, 4..7: X1), the slab of Y and the 128 x 128 operand fully staged
+// in LDS as in gemm_tn_staged_tile (same layout and size: (128 + 16) * FS_STRIDE doubles); the two halves hand over
+// through the staged slab itself (three workgroup barriers). 36 tile products per slab -- the triangles are used,
+// against 64 of the dense product with the full inverse -- in a dependent chain of at most 4 + 4 + 4 tiles.
+// THREADS: threads of the calling workgroup (>= 512); all of them stage, the first 8 waves compute.
+template <int THREADS, int SC1 = 0>
+__device__ __forceinline__ void panel_solve_slab(const int64_t n0, const int64_t N, const double *__restrict__ tinv,
+	double *Y, const int64_t ld, double *fs_lds)
+{
+	static_assert(THREADS >= 512 && THREADS % 64 == 0, "panel_solve_slab: eight waves compute");
+	constexpr int KP = FS_KMAX / 2, PA = (FS_KMAX * KP) / THREADS, PB = (16 * KP + THREADS - 1) / THREADS;
+	static_assert((FS_KMAX * KP) % THREADS == 0, "staging must divide evenly");
+	double *As = fs_lds, *Bs = fs_lds + FS_KMAX * FS_STRIDE;
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int l15 = lane & 15, l4 = lane >> 4, wm = wave * 16;
+	{
+		double2 va[PA], vb[PB];
+#pragma unroll
+		for(int i = 0; i < PA; ++ i) {
+			const int p = tid + i * THREADS, m = p / KP, q = p % KP;
+			// column m of the operand: rows 0 .. m (to the end of its 16-row tile: zeros there, stored by the factorization)
+			va[i] = (2 * q < 16 * (m / 16 + 1)) ? *(const double2*)(tinv + (size_t)m * FS_KMAX + 2 * q) : make_double2(0, 0);
+		}
+#pragma unroll
+		for(int i = 0; i < PB; ++ i) {
+			const int p = tid + i * THREADS, col = p / KP, q = p % KP;
+			int64_t gc = n0 + col;
+			if(gc > N - 1) gc = N - 1;
+			if(p < 16 * KP)
+				vb[i] = *(const double2*)(Y + gc * ld + 2 * q);
+		}
+#pragma unroll
+		for(int i = 0; i < PA; ++ i) {
+			const int p = tid + i * THREADS, m = p / KP, q = p % KP;
+			*(double2*)(&As[m * FS_STRIDE + 2 * q]) = va[i];
+		}
+#pragma unroll
+		for(int i = 0; i < PB; ++ i) {
+			const int p = tid + i * THREADS, col = p / KP, q = p % KP;
+			if(p < 16 * KP)
+				*(double2*)(&Bs[col * FS_STRIDE + 2 * q]) = vb[i];
+		}
+	}
+	__syncthreads();
+	const double *am = As + (wm + l15) * FS_STRIDE + l4, *bn = Bs + l15 * FS_STRIDE + l4;
+	auto chain = [&](const int kb, const int ke) { // sum over k = kb .. ke - 1 of A(k, wm + .)^T B(k, .)
+		v4f64 acc = (v4f64){0, 0, 0, 0};
+#pragma unroll 4
+		for(int k4 = kb; k4 < ke; k4 += 4)
+			acc = __builtin_amdgcn_mfma_f64_16x16x4f64(bn[k4], am[k4], acc, 0, 0, 0);
+		return acc;
+	};
+	auto store_out = [&](const v4f64 x) {
+#pragma unroll
+		for(int r = 0; r < 4; ++ r) {
+			const int64_t n = n0 + l4 + 4 * r;
+			if(n < N) {
+				if(SC1)
+					__hip_atomic_store(&Y[wm + l15 + n * ld], x[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				else
+					Y[wm + l15 + n * ld] = x[r];
+			}
+		}
+	};
+	double *own = Bs + l4 * FS_STRIDE + wm + l15; // this lane's elements of the slab: (row wm + l15, column l4 + 4 r)
+	v4f64 x = (v4f64){0, 0, 0, 0};
+	if(wave < 4)
+		x = chain(0, wm + 16); // X0 = T0^T Y0
+	lds_barrier(); // Y0 has been read
+	if(wave < 4) {
+#pragma unroll
+		for(int r = 0; r < 4; ++ r)
+			own[4 * r * FS_STRIDE] = x[r];
+	}
+	lds_barrier();
+	if(wave < 4)
+		store_out(x);
+	else if(wave < 8) {
+		const v4f64 u = chain(0, 64); // R01^T X0
+#pragma unroll
+		for(int r = 0; r < 4; ++ r)
+			own[4 * r * FS_STRIDE] -= u[r]; // W, in place (each wave only reads its own 16 rows of Y1 here)
+	}
+	lds_barrier();
+	if(wave >= 4 && wave < 8)
+		store_out(chain(64, wm + 16)); // X1 = T1^T W
+}
+
 // --------------------------------------------------------------------------------------------------
 // potrf of one 128 x 128 diagonal block, entirely in LDS, blocked by 16 with MFMA f64 updates.
 //   in : T = upper triangle of the block (global, column-major, ld); padding rows/cols (>= n_valid)
@@ -161,13 +260,6 @@ constexpr int TS = SPP_POTRF_TS;   // LDS column stride of the block image: elem
 constexpr int POTRF_THREADS = 1024;
 constexpr int POTRF_LDS_DOUBLES = NB * TS + 4 * 16 * PT + 2 * NB + 8;
 
-// workgroup barrier that orders LDS accesses only (s_waitcnt lgkmcnt(0) + s_barrier): unlike __syncthreads()
-// it does not wait for outstanding global stores
-__device__ __forceinline__ void lds_barrier()
-{
-	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
 // COH: the block was written by other workgroups of the same launch with write-through stores: read it with
 // agent-scope atomic (sc1) loads -- they bypass this CU's L1, which a plain load could be served from stale
 template <bool COH>
@@ -195,7 +287,12 @@ __device__ __forceinline__ void st_blk(double *p, const double v)
 
 // WT = 2: as 1, and the zeros below the diagonal of the inverse are NOT stored (the buffer is zeroed when it is allocated
 // and nothing else is ever written there): a third fewer stores behind the factorization
-template <bool COH = false, int WT = 0>
+// HALF = 1: `tinv` receives the inverses of the two 64 x 64 diagonal blocks of R_kk and, between them (rows < 64, columns
+// >= 64), R_kk's own off-diagonal block R01 -- not the 64 x 64 block -T0 R01 T1 of the full inverse. The rows of the
+// inverse are accumulated inside the panel loop (G part); of its 84 tile updates 64 belong to that block, and the first
+// panels -- where the R part alone outlasts wave 0's chain -- carry most of them. A row-panel solve with this form runs
+// in two dependent halves of the same total size: X0 = T0^T Y0 ; X1 = T1^T (Y1 - R01^T X0)  (panel_solve_slab).
+template <bool COH = false, int WT = 0, int HALF = 0>
 __device__ __forceinline__ void potrf_diag_body(double *__restrict__ Ablk, int64_t ld, int n_valid, int has_rhs,
 	double *__restrict__ tinv, int *__restrict__ info, int64_t k0, double *sm)
 {
@@ -309,14 +406,19 @@ __device__ __forceinline__ void potrf_diag_body(double *__restrict__ Ablk, int64
 			}
 			for(int e = tid; e < 16 * NB; e += POTRF_THREADS) {
 				const int r = e & (NB - 1), c = j0 + (e >> 7);
+				double v = (r == c) ? 1.0 : 0.0;
+				if(r < c && HALF && (r >> 6) != (c >> 6))
+					v = T[r + c * TS]; // R01 (zeros: a padding column)
+				else if(r < c && r < nv16)
+					v = T[c + r * TS]; // G[c][r] of the valid rows: zeros, assigned there
 				if(WT < 2 || r <= c)
-					st_blk<WT>(&tinv[r + c * NB], (r == c) ? 1.0 : ((r < c && r < nv16) ? T[c + r * TS] : 0.0)); // G[c][r] of the valid rows: zeros, assigned there
+					st_blk<WT>(&tinv[r + c * NB], v);
 			}
 			continue;
 		}
 		const double *Dv = DvB + (J & 1) * 16 * PT, *Gd = GdB + (J & 1) * 16 * PT;
 		// ---- B: row panel. tiles t < J: G part (columns 16 t ..), tiles t >= J: R part (columns 16 (t + 1) ..)
-		if(wave < 7) {
+		if(wave < 7 && !(HALF && wave < (J & ~3))) { // (HALF: no G tiles left of the panel's 64 x 64 block)
 			const int ct = (wave < J) ? wave : wave + 1;
 			double *Y = T + j0 + (ct * 16) * TS;
 			const v4f64 x = tile_atb(Dv, 1, PT, Y, 1, TS, lane); // X[i][j] = sum_k Dinv[k][i] Y[k][j]
@@ -341,7 +443,9 @@ __device__ __forceinline__ void potrf_diag_body(double *__restrict__ Ablk, int64
 		{
 			const int nI = NB / 16 - 1 - J;         // row tiles I = J + 1 .. 7
 			const int nR = nI * (nI + 1) / 2;       // R part: I <= K
-			const int nG = nI * (J + 1);            // G part: Cb = 0 .. J
+			const int gI = HALF ? 3 - (J & 3) : nI;   // G part: rows I = J + 1 .. (HALF: the end of the panel's 64 x 64 block)
+			const int gC = HALF ? (J & 3) + 1 : J + 1, gC0 = HALF ? (J & ~3) : 0; // columns Cb = gC0 .. J
+			const int nG = gI * gC;
 			// tile q -> (I, Ct, gpart); q = 0 is the next diagonal tile (I = K = J + 1)
 			auto decode = [&](int q, int &I, int &Ct, bool &gpart) {
 				gpart = q >= nR;
@@ -355,8 +459,8 @@ __device__ __forceinline__ void potrf_diag_body(double *__restrict__ Ablk, int64
 					Ct = I + rem;
 				} else {
 					const int g = q - nR;
-					I = J + 1 + g / (J + 1);
-					Ct = g % (J + 1);
+					I = J + 1 + g / gC;
+					Ct = gC0 + g % gC;
 				}
 			};
 			if(wave == 0) {
@@ -442,7 +546,7 @@ __device__ __forceinline__ void potrf_diag_body(double *__restrict__ Ablk, int64
 						if(r == c)
 							v = dinv[r];
 						else if(r < c)
-							v = T[c + r * TS]; // G[c][r]
+							v = (HALF && (r >> 6) != (c >> 6)) ? T[r + c * TS] : T[c + r * TS]; // R01[r][c] (final since panel 3) : G[c][r]
 						if(WT < 2 || r <= c)
 							st_blk<WT>(&tinv[r + c * NB], v);
 					}

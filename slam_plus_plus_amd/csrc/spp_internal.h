@@ -230,6 +230,7 @@ struct DenseWork {
 	DevBuf<double> tinv;           // inverse of the current diagonal block (NB x NB)
 	DevBuf<int> info;              // device flag: 0 ok, j+1 = pivot j non-positive
 	DevBuf<double> tinv_all;       // inverses of all diagonal blocks (nblk x NB x NB) kept for the solves
+	int64_t tinv_half = 0;         // > 0: that many of them are in the two-halves form the factorization leaves (completed before a solve)
 	DevBuf<double> xtmp;           // solution of the backward substitution before it replaces y
 	DevBuf<int> flags;             // per block row: epoch of the solve that last published x_b (chain kernel)
 	int epoch = 0;

@@ -1344,12 +1344,12 @@ __device__ __forceinline__ void team_barrier(int *counter, int target, int *abor
 // state the body keeps across them and the allocator (128 VGPRs at 1024 threads) spills inside the hot loops
 __device__ __noinline__ void team_potrf(double *Ablk, int64_t ld, int n_valid, double *tv, int *info, int64_t k0, double *sm)
 {
-	potrf_diag_body<false>(Ablk, ld, n_valid, 0, tv, info, k0, sm);
+	potrf_diag_body<false, 0, 1>(Ablk, ld, n_valid, 0, tv, info, k0, sm);
 }
 
 __device__ __noinline__ void team_panel_tile(int64_t n0, int64_t nright, const double *tv, double *P, int64_t ld, double *sm)
 {
-	gemm_tn_staged_tile<NB, 16, 16, 16, 1, 0, 0, TEAM_THREADS>(0, n0, NB, nright, tv, NB, P, ld, P, ld, sm);
+	panel_solve_slab<TEAM_THREADS>(n0, nright, tv, P, ld, sm);
 }
 
 __device__ __noinline__ void team_update_tile(int64_t m0, int64_t n0, int64_t nright, const double *P, int64_t ld, double *C, double *sm)
