@@ -129,6 +129,7 @@ int spp_free_memory(spp_ctx *ctx)
 	ctx->dense.la_trace.release();
 	ctx->geom_partial.release();
 	ctx->dense.flags.release();
+	ctx->dense.trsv_pay.release();
 	ctx->dense.epoch = 0;
 	ctx->dense.sync.release();
 	ctx->dense.fuse_cnt.release();

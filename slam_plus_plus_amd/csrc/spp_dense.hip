@@ -739,6 +739,261 @@ void trsv_back_chain_kernel(const double *__restrict__ R, int64_t ld, int64_t n,
 		__hip_atomic_store(&flags[b], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// --------------------------------------------------------------------------------------------------
+// Backward substitution, second form: the dependent chain x_last -> ... -> x_0 runs inside ONE workgroup.
+// In trsv_back_chain_kernel every hop of the chain crosses from one workgroup to the next through memory (payload,
+// drain, flag, poll, payload load: ~7 us per block row, 41 of them on Venice). Here
+//   workgroup 0 (the chain) computes  x_b = Tinv_b (w_b - R_{b, b+1} x_{b+1})  for b = last .. 0, the tile right of the
+//                                     diagonal and the block inverse prefetched into registers one hop ahead, x_{b+1}
+//                                     in LDS: nothing on its path waits for another workgroup as long as w_b is there;
+//   workgroup 1 + i (helper of block row b = last - i) streams the rest of the row as the x_k arrive,
+//                                     w_b = y_b - sum_{k > b + 1} R_{b, k} x_k, and hands w_b over -- it is done two
+//                                     hops before the chain needs it.
+// What bounds a hop is what ONE workgroup can fetch (tile + triangular inverse = 208 KB at ~65 GB/s: 3.4 us; without the
+// fetches a hop takes 1.6 us, and the chain never waits for a helper). Two tiles in the chain were slower (more to
+// fetch), four tiles in registers for a deeper prefetch are the CU's whole register file.
+// Hand-overs carry no flag and no fence: every element travels as the pair {value, bits(value) ^ K} (K: a 64-bit
+// constant of this solve), both words written and read with agent-scope relaxed atomics (write-through / L2-bypassing on
+// gfx950). A reader accepts an element when the pair is consistent: a pair from an earlier solve, a pair not yet
+// written and a torn pair (one word new, one old) all fail the test (a false accept needs a 64-bit collision) and are
+// simply read again. So the producer never drains its stores and the consumer needs no second, dependent load.
+// Dispatch order = chain, then helpers from the last block row down: a workgroup only ever waits for data that
+// workgroups dispatched before it produce without waiting for a later one (helper b needs x_k, k > b + 1, which need
+// helpers > b + 1 only), so progress does not depend on how many workgroups are resident. Spins are bounded (err).
+// --------------------------------------------------------------------------------------------------
+struct TrsvPay { double v; unsigned long long c; };
+
+__device__ __forceinline__ void pay_store(TrsvPay *p, double v, unsigned long long K)
+{
+	__hip_atomic_store(&p->v, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	__hip_atomic_store(&p->c, (unsigned long long)__double_as_longlong(v) ^ K, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ bool pay_load(const TrsvPay *p, double &v, unsigned long long K)
+{
+	v = __hip_atomic_load(&p->v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	const unsigned long long c = __hip_atomic_load(&p->c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	return ((unsigned long long)__double_as_longlong(v) ^ c) == K;
+}
+
+// A 128 x 128 tile of a column-major matrix in the registers of 4 waves: lane l holds rows 2 l, 2 l + 1 (one 16-byte
+// load), wave w the columns w, w + 4, ..: one wave load = one whole tile column, 1 KB contiguous. Measured for one
+// workgroup pulling tiles out of the factor (tools/tile_load_bw.hip): 100 GB/s this way, 75 GB/s with 8-byte loads of 64
+// consecutive rows, 38 GB/s with two threads per row -- and the chain below lives on what ONE workgroup can pull.
+template <int NW>
+struct TileRegs { double2 v[NB / NW]; };
+
+// TRI: the tile is upper triangular (a block inverse): a lane whose rows lie below column c does not fetch it
+template <bool TRI, int NW>
+__device__ __forceinline__ void tile_fetch(TileRegs<NW> &t, const double *T, const int64_t ld, const int lane, const int wave)
+{
+#pragma unroll
+	for(int j = 0; j < NB / NW; ++ j) {
+		const int c = wave + NW * j;
+		// (address = wave-uniform column base in scalar registers + one unsigned 32-bit lane offset)
+		const double *col = T + (int64_t)c * ld;
+		const uint32_t loff = 2u * (uint32_t)lane;
+		if(!TRI || 2 * lane <= c)
+			t.v[j] = *(const double2*)(col + loff);
+		else
+			t.v[j] = make_double2(0, 0);
+	}
+}
+
+// a += tile . x over this wave's columns (columns >= nv masked: the padding of the last block holds the rhs column)
+template <int NW>
+__device__ __forceinline__ void tile_dot(double2 &a, const TileRegs<NW> &t, const double *x, const int wave, const int nv)
+{
+	double2 s0 = make_double2(0, 0), s1 = make_double2(0, 0);
+	if(nv >= NB) {
+#pragma unroll
+		for(int j = 0; j < NB / NW; j += 2) {
+			const double x0 = x[wave + NW * j], x1 = x[wave + NW * j + NW];
+			s0.x += t.v[j].x * x0; s0.y += t.v[j].y * x0;
+			s1.x += t.v[j + 1].x * x1; s1.y += t.v[j + 1].y * x1;
+		}
+	} else {
+#pragma unroll
+		for(int j = 0; j < NB / NW; ++ j) {
+			const int c = wave + NW * j;
+			const double xv = (c < nv) ? x[c] : 0.0; // (wave-uniform)
+			s0.x += (c < nv) ? t.v[j].x * xv : 0.0;
+			s0.y += (c < nv) ? t.v[j].y * xv : 0.0;
+		}
+	}
+	a.x += s0.x + s1.x;
+	a.y += s0.y + s1.y;
+}
+
+// NW waves (8: measured 140 us on the Venice system, 4 waves 194 us, 16 waves 142 us)
+template <int NW>
+__global__ __launch_bounds__(64 * NW)
+void trsv_back_chain2_kernel(const double *__restrict__ R, int64_t ld, int64_t n, int nblk,
+	const double *__restrict__ tinv_all, double *y, TrsvPay *xpay, TrsvPay *wpay, unsigned long long K, int *err)
+{
+	__shared__ double xs[2][NB];   // chain: x_b in xs[b & 1] ; helper: xs[0 / 1] = the x_k being applied
+	__shared__ double zs[NB];
+	__shared__ __attribute__((aligned(16))) double part[NW][NB]; // the waves' partial sums per row
+	__shared__ int ok[2];
+	constexpr int L = 1; // tiles right of the diagonal the chain applies itself (two measured slower: the chain is bound by what it fetches)
+	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // (wave: a scalar -- column bases stay in scalar registers)
+	constexpr int SPIN_MAX = 1 << 22;
+	auto part_sum = [&](const int row) {
+		double s = 0;
+#pragma unroll
+		for(int w = 0; w < NW; w += 2)
+			s += part[w][row] + part[w + 1][row];
+		return s;
+	};
+	// (lds_barrier, not __syncthreads: the latter waits for every outstanding global load -- the prefetched tiles)
+	if(blockIdx.x > 0) {
+		// ---- helper of block row b
+		const int b = nblk - (int)blockIdx.x;
+		const int64_t r0 = (int64_t)NB * b;
+		TileRegs<NW> ra, rb; // the tile being applied and the one after it (static slots: no indexed register arrays)
+		const int klast = b + L + 1; // tiles k = nblk - 1 .. klast
+		double2 acc = make_double2(0, 0);
+		const double yb = (tid < NB && r0 + tid < n) ? y[r0 + tid] : 0.0; // (fetched now: not behind the last x_k)
+		bool alive = true;
+		// one tile: wait for x_k (slot: which half of xs), apply, refill the register slot with tile k - 2
+		auto step = [&](const int k, TileRegs<NW> &t, const int slot) {
+			double *xk = xs[slot];
+			if(tid < 64) { // one wave polls the payload of x_k: two elements per lane
+				const TrsvPay *src = xpay + (size_t)k * NB + 2 * tid;
+				double v0 = 0, v1 = 0;
+				int spins = 0;
+				for(;;) {
+					const bool g0 = pay_load(src, v0, K), g1 = pay_load(src + 1, v1, K);
+					if(__all(g0 && g1) || ++ spins >= SPIN_MAX)
+						break;
+					__builtin_amdgcn_s_sleep(2);
+				}
+				xk[2 * tid] = v0;
+				xk[2 * tid + 1] = v1;
+				if(tid == 0)
+					ok[slot] = spins < SPIN_MAX;
+			}
+			lds_barrier();
+			if(!ok[slot]) {
+				if(tid == 0)
+					*err = 1;
+				alive = false;
+				return;
+			}
+			const int64_t c0 = (int64_t)NB * k;
+			const int nvk = (int)((n - c0 < NB) ? (n - c0) : NB); // real columns of block k (its padding holds the rhs)
+			double2 s = make_double2(0, 0);
+			tile_dot<NW>(s, t, xk, wave, nvk);
+			acc.x -= s.x;
+			acc.y -= s.y;
+			asm volatile("" ::: "memory"); // (the refill reuses the registers just released)
+			__builtin_amdgcn_sched_barrier(0);
+			if(k - 2 >= klast)
+				tile_fetch<false, NW>(t, R + r0 + (int64_t)NB * (k - 2) * ld, ld, lane, wave); // in flight while this workgroup waits for x_{k-1}
+			// (no second barrier: x_{k-1} goes to the other half of xs, and the barrier of that round orders the write of
+			// x_{k-2} behind this round's reads)
+		};
+		int k = nblk - 1;
+		if(k >= klast)
+			tile_fetch<false, NW>(ra, R + r0 + (int64_t)NB * k * ld, ld, lane, wave);
+		if(k - 1 >= klast)
+			tile_fetch<false, NW>(rb, R + r0 + (int64_t)NB * (k - 1) * ld, ld, lane, wave);
+		while(k >= klast && alive) {
+			step(k, ra, 0);
+			-- k;
+			if(k < klast || !alive)
+				break;
+			step(k, rb, 1);
+			-- k;
+		}
+		if(!alive)
+			return;
+		*(double2*)&part[wave][2 * lane] = acc;
+		lds_barrier();
+		if(tid < NB)
+			pay_store(wpay + (size_t)b * NB + tid, yb + part_sum(tid), K);
+		return;
+	}
+	// ---- the chain. Threads 0 .. 127 own row tid of the current block for the hand-overs (w in, x out).
+	// Tile (b, b+1) and the block inverse of hop b are fetched one hop ahead, each right after its use. (Two hops ahead
+	// would need four tiles in registers = the whole register file of the CU: what one workgroup can pull, 100 GB/s and
+	// latency-bound, is what bounds a hop -- 208 KB in ~3.4 us.)
+	TileRegs<NW> t1a, tva;
+	auto ask_w = [&](int b, double &v, unsigned long long &c) { // both words of w_b[tid], used one hop later
+		const TrsvPay *p = wpay + (size_t)b * NB + tid;
+		v = __hip_atomic_load(&p->v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		c = __hip_atomic_load(&p->c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	};
+	auto fetch_tile = [&](int b, TileRegs<NW> &t1) { // tile (b, b+1)
+		if(b >= 0 && b + 1 < nblk)
+			tile_fetch<false, NW>(t1, R + (int64_t)NB * b + (int64_t)NB * (b + 1) * ld, ld, lane, wave);
+	};
+	auto fetch_inv = [&](int b, TileRegs<NW> &tv) {
+		if(b >= 0)
+			tile_fetch<true, NW>(tv, tinv_all + (size_t)b * NB * NB, NB, lane, wave);
+	};
+	double wv = 0;
+	unsigned long long wc = 0;
+	auto hop = [&](const int b, TileRegs<NW> &t1, TileRegs<NW> &tv) {
+		const int64_t r0 = (int64_t)NB * b;
+		// A: this wave's share of R_{b, b+1} x_{b+1}
+		{
+			double2 s = make_double2(0, 0);
+			if(b + 1 < nblk) {
+				const int64_t c0 = (int64_t)NB * (b + 1);
+				tile_dot<NW>(s, t1, xs[(b + 1) & 1], wave, (int)((n - c0 < NB) ? (n - c0) : NB));
+			}
+			*(double2*)&part[wave][2 * lane] = s;
+		}
+		// (compiler fence: the prefetch must reuse the registers the products above just released -- hoisted above them
+		// it would double the register need)
+		asm volatile("" ::: "memory");
+		__builtin_amdgcn_sched_barrier(0);
+		fetch_tile(b - 1, t1);
+		lds_barrier();
+		// B: z = w_b - sum. w_b was asked for one hop ago; read again until the pair is consistent (the helper is
+		// normally far ahead)
+		if(tid < NB) {
+			int spins = 0;
+			while(((unsigned long long)__double_as_longlong(wv) ^ wc) != K && spins < SPIN_MAX) {
+				__builtin_amdgcn_s_sleep(1);
+				ask_w(b, wv, wc);
+				++ spins;
+			}
+			if(spins >= SPIN_MAX)
+				*err = 1; // (the hop goes on with garbage: every workgroup still drains)
+			zs[tid] = wv - part_sum(tid);
+		}
+		lds_barrier();
+		// C: this wave's share of Tinv_b z
+		{
+			double2 s = make_double2(0, 0);
+			tile_dot<NW>(s, tv, zs, wave, (int)((n - r0 < NB) ? (n - r0) : NB));
+			*(double2*)&part[wave][2 * lane] = s;
+		}
+		asm volatile("" ::: "memory");
+		__builtin_amdgcn_sched_barrier(0);
+		fetch_inv(b - 1, tv);
+		lds_barrier();
+		// D: x_b out
+		if(tid < NB) {
+			const double xr = part_sum(tid);
+			xs[b & 1][tid] = xr;
+			pay_store(xpay + (size_t)b * NB + tid, xr, K);
+			if(r0 + tid < n)
+				y[r0 + tid] = xr; // in place: the helper of this block row read y_b before it handed over w_b
+			if(b > 0)
+				ask_w(b - 1, wv, wc); // (two hops ahead measured slower: the wait for w_b then also covers the younger request)
+		}
+		lds_barrier();
+	};
+	fetch_inv(nblk - 1, tva);
+	if(tid < NB)
+		ask_w(nblk - 1, wv, wc);
+	for(int b = nblk - 1; b >= 0; -- b)
+		hop(b, t1a, tva);
+}
+
 __global__ void set_info_kernel(int *info) { info[0] = 0; info[1] = 0; }
 
 // padding diagonal = 1 (rows/cols >= n); the rows >= n of the rhs column (column n) are cleared so
@@ -1408,10 +1663,39 @@ void dense_potrs_upper(spp_ctx *ctx, const double *d_R, int64_t n, int64_t ld, d
 	}
 	static int chain = -1;
 	if(chain < 0) {
-		const char *e = getenv("SPP_TRSV_CHAIN");
-		chain = e ? atoi(e) : 1;
+		const char *e = getenv("SPP_TRSV_CHAIN"); // 2: the chain inside one workgroup (default), 1: a workgroup per hop (round 2), 0: a launch per hop (round 1)
+		chain = e ? atoi(e) : 2;
 	}
-	if(chain && nblk > 1 && nblk <= 1024) {
+	int use_chain = chain;
+	{
+		// both chain kernels tell one solve from the next by a kernel argument (epoch / check constant): a captured
+		// launch would replay it stale -- inside a stream capture the substitution is a launch per block row
+		hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+		if(hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone)
+			use_chain = 0;
+	}
+	if(use_chain == 2 && nblk > 1 && nblk <= 4096) {
+		DenseWork &dw = ctx->dense;
+		const size_t need = (size_t)nblk * NB * 4; // x and w, two words per element
+		if(dw.trsv_pay.cap < need) {
+			dw.trsv_pay.reserve(need);
+			SPP_HIP_CHECK(hipMemsetAsync(dw.trsv_pay.p, 0, dw.trsv_pay.cap * sizeof(double), s));
+		}
+		if(!dw.h_chain_err) {
+			SPP_HIP_CHECK(hipHostMalloc((void**)&dw.h_chain_err, sizeof(int), hipHostMallocDefault));
+			*dw.h_chain_err = 0;
+		}
+		++ dw.epoch;
+		// the check constant of this solve: odd multiples of a 64-bit odd constant are distinct and non-zero for 2^63 solves
+		const unsigned long long K = (2ull * (unsigned long long)(unsigned)dw.epoch + 1ull) * 0x9E3779B97F4A7C15ull;
+		TrsvPay *xpay = (TrsvPay*)dw.trsv_pay.p, *wpay = xpay + (size_t)nblk * NB;
+		hipLaunchKernelGGL((trsv_back_chain2_kernel<8>), dim3((unsigned)nblk + 1), dim3(512), 0, s,
+			d_R, ld, n, (int)nblk, dw.tinv_all.p, d_b, xpay, wpay, K, dw.info.p + 1);
+		SPP_HIP_CHECK(hipGetLastError());
+		SPP_HIP_CHECK(hipMemcpyAsync(dw.h_chain_err, dw.info.p + 1, sizeof(int), hipMemcpyDeviceToHost, s));
+		return;
+	}
+	if(use_chain && nblk > 1 && nblk <= 1024) {
 		// one launch, the dependent chain runs through device flags (info[1] = timeout flag)
 		DenseWork &dw = ctx->dense;
 		if(dw.flags.cap < (size_t)nblk) {
