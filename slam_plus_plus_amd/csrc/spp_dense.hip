@@ -1810,23 +1810,41 @@ double microbench_ctile(spp_ctx *ctx, int n, int iters)
 	return 2.0 * n * n * sizeof(double) * iters / (ms * 1e-3) * 1e-9;
 }
 
+// Issue rate of v_mfma_f64_16x16x4 with the operand pattern of a real tile product: a 2 x 2 register outer product fed
+// from eight + two distinct operand registers holding data (tools/mfma_rate2.hip). One operand pair reused by every
+// instruction -- the loop of rounds 1-2 -- measures 46-48 TFLOP/s on the same part; this pattern 67.
 __global__ __launch_bounds__(256)
 void mfma_f64_peak_kernel(double *out, int iters)
 {
-	v4f64 acc[8];
+	double fn[8], fm[2];
 #pragma unroll
 	for(int i = 0; i < 8; ++ i)
-		acc[i] = (v4f64){0, 0, 0, 0};
-	double a = threadIdx.x * 1e-3, b = 1.0 + blockIdx.x * 1e-6;
+		fn[i] = 0.25 + 1e-3 * ((threadIdx.x * 7 + i * 13) & 63);
+#pragma unroll
+	for(int i = 0; i < 2; ++ i)
+		fm[i] = 0.5 - 1e-3 * ((threadIdx.x * 5 + i * 11 + blockIdx.x) & 63);
+	v4f64 acc[2][2];
+#pragma unroll
+	for(int i = 0; i < 2; ++ i)
+#pragma unroll
+		for(int j = 0; j < 2; ++ j)
+			acc[i][j] = (v4f64){0, 0, 0, 0};
 	for(int it = 0; it < iters; ++ it) {
 #pragma unroll
-		for(int i = 0; i < 8; ++ i)
-			acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+		for(int r = 0; r < 4; ++ r)
+#pragma unroll
+			for(int i = 0; i < 2; ++ i)
+#pragma unroll
+				for(int j = 0; j < 2; ++ j)
+					acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fn[i + 2 * r], fm[j], acc[i][j], 0, 0, 0);
+		fm[0] = -fm[0]; // (the sums stay bounded, the operands keep changing)
 	}
 	double s = 0;
 #pragma unroll
-	for(int i = 0; i < 8; ++ i)
-		s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+	for(int i = 0; i < 2; ++ i)
+#pragma unroll
+		for(int j = 0; j < 2; ++ j)
+			s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
 	out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
@@ -1847,8 +1865,8 @@ double microbench_mfma_f64(spp_ctx *ctx, int iters)
 	SPP_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
 	(void)hipEventDestroy(e0);
 	(void)hipEventDestroy(e1);
-	// per wave: iters * 8 MFMAs of 16*16*4*2 flops
-	double flops = (double)nblk * 4 * (double)iters * 8 * 2048.0;
+	// per wave: iters * 16 MFMAs of 16*16*4*2 flops
+	double flops = (double)nblk * 4 * (double)iters * 16 * 2048.0;
 	return flops / (ms * 1e-3) * 1e-12;
 }
 
