@@ -130,6 +130,9 @@ int spp_free_memory(spp_ctx *ctx)
 	ctx->geom_partial.release();
 	ctx->dense.flags.release();
 	ctx->dense.trsv_pay.release();
+	ctx->dense.tail_pub.release();
+	ctx->dense.tail_dinv.release();
+	ctx->dense.tail_epoch = 0;
 	ctx->dense.epoch = 0;
 	ctx->dense.sync.release();
 	ctx->dense.fuse_cnt.release();

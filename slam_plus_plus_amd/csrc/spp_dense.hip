@@ -581,6 +581,7 @@ void update_potrf_kernel(int64_t M, int64_t N, const double *P, int64_t ld, doub
 
 } // namespace spp
 #include "spp_dense_la.h" // the lookahead schedule: persistent chain kernel + one bulk launch per step
+#include "spp_dense_tail.h" // the streamed tail: one workgroup per tile, the factorization passed on 16 rows at a time
 namespace spp {
 
 // backward substitution step for block column k (rows/cols k0 .. k0 + NB):
@@ -1347,6 +1348,90 @@ static bool flag_schedule_usable(spp_ctx *ctx)
 	return dw.sync_state == 1;
 }
 
+// The streamed tail (spp_dense_tail.h): everything behind row panel k -- the update of step k, then steps k + 1 .. --
+// as one launch, when the trailing matrix is a full factorization (every tile row a pivot block) of few enough tiles
+// for one workgroup per CU. Returns false when it does not apply (the per-step schedule goes on).
+static bool launch_dense_tail(spp_ctx *ctx, double *d_A, int64_t ld, int64_t rows, int64_t ncols, int64_t nsteps, int64_t k, bool has_rhs)
+{
+	static int enabled = -1;
+	if(enabled < 0) {
+		const char *e = getenv("SPP_DENSE_TAIL"); // 1: the streamed tail; 0: the per-step single-stream tail of round 2
+		enabled = e ? atoi(e) : 0;
+	}
+	DenseWork &dw = ctx->dense;
+	const int64_t c1 = (k + 1) * NB;
+	if(!enabled || k + 1 >= nsteps || nsteps * NB < rows || (dw.ident_from >= 0 && dw.ident_from < rows))
+		return false;
+	const int Tr = (int)(nsteps - (k + 1)), Tc = (int)((ncols - c1 + NB - 1) / NB);
+	if(Tr < 1 || Tc < Tr || Tc > Tr + 1)
+		return false;
+	const int ntile = Tr * Tc - Tr * (Tr - 1) / 2;
+	int dev = 0, ncu = 0;
+	SPP_HIP_CHECK(hipGetDevice(&dev));
+	SPP_HIP_CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+	if(ntile > ncu)
+		return false;
+	hipStream_t s = ctx->stream;
+	static uint64_t attr_seen = 0;
+	if(first_on_this_device(attr_seen))
+		SPP_HIP_CHECK(hipFuncSetAttribute((const void*)dense_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+			TAIL_LDS_DOUBLES * (int)sizeof(double)));
+	if(dw.tail_pub.cap < (size_t)Tr * Tc) {
+		dw.tail_pub.reserve(std::max<size_t>((size_t)Tr * Tc, 24 * 25));
+		SPP_HIP_CHECK(hipMemsetAsync(dw.tail_pub.p, 0, dw.tail_pub.cap * sizeof(int), s));
+		dw.tail_epoch = 0;
+	}
+	if(dw.tail_dinv.cap < (size_t)Tr * 8 * 256)
+		dw.tail_dinv.reserve(std::max<size_t>((size_t)Tr * 8 * 256, (size_t)24 * 8 * 256));
+	if(++ dw.tail_epoch >= (1 << 26)) { // (28 bits of epoch in a counter word)
+		SPP_HIP_CHECK(hipMemsetAsync(dw.tail_pub.p, 0, dw.tail_pub.cap * sizeof(int), s));
+		dw.tail_epoch = 1;
+	}
+	TailArgs a;
+	a.A = d_A;
+	a.ld = ld;
+	a.rows = rows;
+	a.ncols = ncols;
+	a.c0 = c1;
+	a.have_pre = 1;
+	a.Tr = Tr;
+	a.Tc = Tc;
+	a.has_rhs = has_rhs ? 1 : 0;
+	a.tinv = dw.tinv_all.p + (size_t)(k + 1) * NB * NB;
+	a.dbuf = dw.tail_dinv.p;
+	a.pub = dw.tail_pub.p;
+	a.epoch = dw.tail_epoch;
+	a.info = dw.info.p;
+	a.abort = dw.info.p + 2;
+	a.timeout_ticks = (long long)(500.0 * 1e5);
+	static int trace_env = -1;
+	if(trace_env < 0) {
+		const char *e = getenv("SPP_TAIL_TRACE"); // n: the n-th launch prints per tile row when its diagonal tile had all updates, was factored, and when the first panel tile started / ended
+		trace_env = e ? atoi(e) : 0;
+	}
+	static int launches = 0;
+	DevBuf<long long> trace;
+	a.trace = nullptr;
+	if(trace_env && ++ launches == trace_env) {
+		trace.reserve((size_t)Tr * 8);
+		SPP_HIP_CHECK(hipMemsetAsync(trace.p, 0, (size_t)Tr * 8 * sizeof(long long), s));
+		a.trace = trace.p;
+	}
+	hipLaunchKernelGGL(dense_tail_kernel, dim3((unsigned)ntile), dim3(POTRF_THREADS), TAIL_LDS_DOUBLES * sizeof(double), s, a);
+	SPP_HIP_CHECK(hipGetLastError());
+	if(a.trace) {
+		std::vector<long long> h((size_t)Tr * 8);
+		SPP_HIP_CHECK(hipStreamSynchronize(s));
+		SPP_HIP_CHECK(hipMemcpy(h.data(), trace.p, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+		fprintf(stderr, "[spp] streamed tail, %d tile rows (us from the launch's first stamp): diagonal tile: updates complete / factored+inverted | first panel tile: first row tile seen / last seen / last published\n", Tr);
+		const long long t0 = h[0];
+		for(int i = 0; i < Tr; ++ i)
+			fprintf(stderr, "  row %2d  start %7.1f  updated %7.1f  done %7.1f | %7.1f %7.1f %7.1f\n", i, (h[8 * i] - t0) * 0.01, (h[8 * i + 1] - t0) * 0.01,
+				(h[8 * i + 2] - t0) * 0.01, h[8 * i + 3] ? (h[8 * i + 3] - t0) * 0.01 : 0.0, h[8 * i + 4] ? (h[8 * i + 4] - t0) * 0.01 : 0.0, h[8 * i + 5] ? (h[8 * i + 5] - t0) * 0.01 : 0.0);
+	}
+	return true;
+}
+
 // The two-stream schedule. Chain (ctx stream): fused [tile row k+1 <- panel k, potrf_diag(k+1)], panel solve k+1.
 // Bulk (CU-masked second stream): everything below the tile row, handed over right after the panel solve; once the
 // trailing matrix is at most 2560 rows the whole step runs on the chain stream (one fused launch updates every
@@ -1526,6 +1611,10 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 				bulk_pending = false;
 			}
 			const double *P = d_A + k0 + c1 * ld;
+			if(allow_fused && launch_dense_tail(ctx, d_A, ld, rows, ncols, nsteps, k, has_rhs)) {
+				dw.tinv_half = k + 1; // (the streamed tail stores whole block inverses)
+				break;
+			}
 			if(fused && k + 1 < nsteps && rows - c1 >= NB) {
 				// one launch: every trailing tile <- panel k, the next diagonal block factored as soon as ITS tile is done
 				fused_update_potrf(c1, rows - c1, k0, k + 1);
@@ -1622,6 +1711,12 @@ int dense_info_fetch(spp_ctx *ctx, bool *dag_aborted)
 		}
 		throw Error(SPP_E_HIP, "sparse factorization: a front timed out waiting for another front's flag; "
 			"the following calls launch level by level");
+	}
+	if(h_info[2] && h_info[0]) {
+		// the streamed tail raises the abort word when a diagonal block is not positive definite (its consumers give up
+		// waiting): that is a failed factorization, not a lost hand-over
+		SPP_HIP_CHECK(hipMemset(ctx->dense.info.p + 2, 0, sizeof(int)));
+		return h_info[0];
 	}
 	if(h_info[2]) { // a cross-stream flag wait timed out: the result is garbage, the flag hand-offs stay off
 		SPP_HIP_CHECK(hipMemset(ctx->dense.info.p + 2, 0, sizeof(int)));

@@ -259,6 +259,17 @@ constexpr int NB = DENSE_NB;
 constexpr int TS = SPP_POTRF_TS;   // LDS column stride of the block image: element (r, c) at r + c * TS
 constexpr int POTRF_THREADS = 1024;
 constexpr int POTRF_LDS_DOUBLES = NB * TS + 4 * 16 * PT + 2 * NB + 8;
+constexpr int POTRF_LDS_DOUBLES_INV2 = NB * TS + (2 + NB / 16) * 16 * PT + 2 * NB + 8; // HALF = 2: a G_JJ slot per panel
+static_assert(POTRF_LDS_DOUBLES_INV2 * 8 <= 160 * 1024, "the diagonal-block factorization's LDS exceeds a CU");
+
+// HALF = 2 streams the factorization out: after panel J the rows 16 J .. 16 J + 15 of R (stored write-through) and the
+// inverse of their diagonal tile (dbuf + 256 J, Dinv[k][i] at k + 16 i) are complete in memory and *flag = base + J + 1
+struct PotrfPub {
+	int *flag = nullptr;
+	int base = 0;
+	double *dbuf = nullptr;
+	int *abort = nullptr; // raised when the block is not positive definite (the consumers of the stream give up)
+};
 
 // COH: the block was written by other workgroups of the same launch with write-through stores: read it with
 // agent-scope atomic (sc1) loads -- they bypass this CU's L1, which a plain load could be served from stale
@@ -292,16 +303,22 @@ __device__ __forceinline__ void st_blk(double *p, const double v)
 // inverse are accumulated inside the panel loop (G part); of its 84 tile updates 64 belong to that block, and the first
 // panels -- where the R part alone outlasts wave 0's chain -- carry most of them. A row-panel solve with this form runs
 // in two dependent halves of the same total size: X0 = T0^T Y0 ; X1 = T1^T (Y1 - R01^T X0)  (panel_solve_slab).
-template <bool COH = false, int WT = 0, int HALF = 0>
+// HALF = 2 (the streamed tail of the dense factor, spp_dense_tail.h): NO rows of the inverse inside the panel loop -- the
+// loop is the factorization alone, 46 k cycles without its prologue --, every finished row tile is published (PotrfPub),
+// and the whole inverse is formed AFTER the loop, off the critical chain, by recursive doubling over the 16 x 16 tiles.
+// PRELOADED: the block's upper triangle is already in the LDS image (the workgroup accumulated it there).
+template <bool COH = false, int WT = 0, int HALF = 0, bool PRELOADED = false>
 __device__ __forceinline__ void potrf_diag_body(double *__restrict__ Ablk, int64_t ld, int n_valid, int has_rhs,
-	double *__restrict__ tinv, int *__restrict__ info, int64_t k0, double *sm)
+	double *__restrict__ tinv, int *__restrict__ info, int64_t k0, double *sm, const PotrfPub pub = PotrfPub())
 {
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	SPP_STAMP(0, 0);
+	constexpr int GD_SLOTS = (HALF == 2) ? NB / 16 : 2;
 	double *T = sm;                  // NB x NB image, stride TS
 	double *DvB = T + NB * TS;       // 2 x Dinv[k][i] at Dv[k + i * PT] (upper triangular, zeros below)
-	double *GdB = DvB + 2 * 16 * PT; // 2 x G_JJ[r][c] = Dinv[c][r] at Gd[r + c * PT] (lower triangular incl. diagonal)
-	double *dinv = GdB + 2 * 16 * PT; // 1 / R[j][j]
+	double *GdB = DvB + 2 * 16 * PT; // G_JJ[r][c] = Dinv[c][r] at Gd[r + c * PT] (lower triangular incl. diagonal): two slots by panel parity, or (HALF = 2) one per panel
+	auto gd_slot = [&](int J) { return GdB + ((HALF == 2) ? J : (J & 1)) * 16 * PT; };
+	double *dinv = GdB + GD_SLOTS * 16 * PT; // 1 / R[j][j]
 	double *yv = dinv + NB;          // carried right-hand side
 	int *fail = (int*)(yv + NB);
 	const int l15 = lane & 15, l4 = lane >> 4;
@@ -310,7 +327,7 @@ __device__ __forceinline__ void potrf_diag_body(double *__restrict__ Ablk, int64
 	// Prologue. The first diagonal tile only needs its own 16 x 16 entries: wave 0 fetches them and starts
 	// the elimination (5 500 cycles) while the other 15 waves stream in the rest of the block (6 500 cycles).
 	// Not possible when the carried right-hand side sits inside that tile (n_valid < 16): plain order then.
-	const bool fast0 = !(rhs_col >= 0 && rhs_col < 16);
+	const bool fast0 = !PRELOADED && !(rhs_col >= 0 && rhs_col < 16);
 	if(tid == 0)
 		*fail = 0;
 	if(fast0) {
@@ -325,7 +342,7 @@ __device__ __forceinline__ void potrf_diag_body(double *__restrict__ Ablk, int64
 				T[l15 + (l4 + 4 * t) * TS] = v[t];
 			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 			__builtin_amdgcn_wave_barrier();
-			diag_tile_factor<TS>(T, DvB, GdB, dinv, 0, lane, fail, info, k0);
+			diag_tile_factor<TS>(T, DvB, gd_slot(0), dinv, 0, lane, fail, info, k0);
 		} else {
 			// 16-byte pieces of the block without its first tile, spread over the 960 threads of waves 1..15;
 			// all of a thread's loads are in flight before its first LDS store
@@ -360,7 +377,7 @@ __device__ __forceinline__ void potrf_diag_body(double *__restrict__ Ablk, int64
 			T[tid + rhs_col * TS] = (tid == rhs_col) ? 1.0 : 0.0; // the rhs column becomes plain padding
 		__syncthreads();
 	} else {
-		{
+		if(!PRELOADED) {
 			double2 v[NB * NB / 2 / POTRF_THREADS];
 #pragma unroll
 			for(int t = 0; t < NB * NB / 2 / POTRF_THREADS; ++ t) {
@@ -385,14 +402,17 @@ __device__ __forceinline__ void potrf_diag_body(double *__restrict__ Ablk, int64
 			T[tid + rhs_col * TS] = (tid == rhs_col) ? 1.0 : 0.0; // the rhs column becomes plain padding
 		__syncthreads();
 		if(wave == 0)
-			diag_tile_factor<TS>(T, DvB, GdB, dinv, 0, lane, fail, info, k0);
+			diag_tile_factor<TS>(T, DvB, gd_slot(0), dinv, 0, lane, fail, info, k0);
 		__syncthreads();
 	}
 	SPP_STAMP(2, 0);
 
 	for(int J = 0; J < NB / 16; ++ J) {
-		if(*fail)
+		if(*fail) {
+			if(pub.abort && tid == 0)
+				__hip_atomic_store(pub.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			return;
+		}
 		SPP_STAMP(3 + 6 * J, 0);
 		const int j0 = J * 16;
 		if(j0 >= n_valid) {
@@ -403,6 +423,21 @@ __device__ __forceinline__ void potrf_diag_body(double *__restrict__ Ablk, int64
 				const int r = j0 + (e & 15), c = j0 + (e >> 4);
 				if(r <= c && c != rhs_col)
 					st_blk<WT>(&Ablk[r + (int64_t)c * ld], (r == c) ? 1.0 : 0.0);
+			}
+			if(HALF == 2) { // identity panel: its diagonal tile of the inverse is the identity; published like any other
+				if(tid < 256) {
+					const double v = ((tid & 15) == (tid >> 4)) ? 1.0 : 0.0;
+					gd_slot(J)[(tid & 15) + (tid >> 4) * PT] = v;
+					if(pub.dbuf)
+						st_blk<1>(&pub.dbuf[256 * J + tid], v);
+				}
+				if(pub.flag) {
+					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+					lds_barrier();
+					if(tid == 0)
+						__hip_atomic_store(pub.flag, pub.base + J + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
+				continue;
 			}
 			for(int e = tid; e < 16 * NB; e += POTRF_THREADS) {
 				const int r = e & (NB - 1), c = j0 + (e >> 7);
@@ -416,9 +451,9 @@ __device__ __forceinline__ void potrf_diag_body(double *__restrict__ Ablk, int64
 			}
 			continue;
 		}
-		const double *Dv = DvB + (J & 1) * 16 * PT, *Gd = GdB + (J & 1) * 16 * PT;
+		const double *Dv = DvB + (J & 1) * 16 * PT, *Gd = gd_slot(J);
 		// ---- B: row panel. tiles t < J: G part (columns 16 t ..), tiles t >= J: R part (columns 16 (t + 1) ..)
-		if(wave < 7 && !(HALF && wave < (J & ~3))) { // (HALF: no G tiles left of the panel's 64 x 64 block)
+		if(wave < 7 && !(HALF == 1 && wave < (J & ~3)) && !(HALF == 2 && wave < J)) { // (HALF: no G tiles left of the panel's 64 x 64 block; 2: none)
 			const int ct = (wave < J) ? wave : wave + 1;
 			double *Y = T + j0 + (ct * 16) * TS;
 			const v4f64 x = tile_atb(Dv, 1, PT, Y, 1, TS, lane); // X[i][j] = sum_k Dinv[k][i] Y[k][j]
@@ -445,7 +480,7 @@ __device__ __forceinline__ void potrf_diag_body(double *__restrict__ Ablk, int64
 			const int nR = nI * (nI + 1) / 2;       // R part: I <= K
 			const int gI = HALF ? 3 - (J & 3) : nI;   // G part: rows I = J + 1 .. (HALF: the end of the panel's 64 x 64 block)
 			const int gC = HALF ? (J & 3) + 1 : J + 1, gC0 = HALF ? (J & ~3) : 0; // columns Cb = gC0 .. J
-			const int nG = gI * gC;
+			const int nG = (HALF == 2) ? 0 : gI * gC;
 			// tile q -> (I, Ct, gpart); q = 0 is the next diagonal tile (I = K = J + 1)
 			auto decode = [&](int q, int &I, int &Ct, bool &gpart) {
 				gpart = q >= nR;
@@ -473,7 +508,7 @@ __device__ __forceinline__ void potrf_diag_body(double *__restrict__ Ablk, int64
 						D[(l4 + 4 * r) + l15 * TS] -= d[r];
 					__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 					__builtin_amdgcn_wave_barrier();
-					diag_tile_factor<TS>(T, DvB + ((J + 1) & 1) * 16 * PT, GdB + ((J + 1) & 1) * 16 * PT, dinv,
+					diag_tile_factor<TS>(T, DvB + ((J + 1) & 1) * 16 * PT, gd_slot(J + 1), dinv,
 						j0 + 16, lane, fail, info, k0);
 				}
 			} else {
@@ -540,7 +575,7 @@ __device__ __forceinline__ void potrf_diag_body(double *__restrict__ Ablk, int64
 						if(r <= c && c != rhs_col)
 							st_blk<WT>(&Ablk[r + (int64_t)c * ld], T[r + c * TS]);
 					}
-					for(int e = t15; e < 16 * NB; e += (NW - 1) * 64) { // inverse: columns j0 .. j0+15, all 128 rows
+					for(int e = t15; HALF != 2 && e < 16 * NB; e += (NW - 1) * 64) { // inverse: columns j0 .. j0+15, all 128 rows
 						const int r = e & (NB - 1), c = j0 + (e >> 7);
 						double v = 0;
 						if(r == c)
@@ -559,16 +594,84 @@ __device__ __forceinline__ void potrf_diag_body(double *__restrict__ Ablk, int64
 						s += T[(j0 + k) + ti * TS] * yv[j0 + k];
 					yv[ti] -= s;
 				}
+				if(HALF == 2 && pub.flag) {
+					// streamed: the inverse of this panel's diagonal tile goes out beside its rows (wave 15), and every storing
+					// wave drains before the barrier below -- the stores have had the rest of wave 0's elimination to complete
+					if(wave == NW - 1 && pub.dbuf) {
+#pragma unroll
+						for(int t = 0; t < 4; ++ t) {
+							const int e = lane + 64 * t; // Dinv[k][i] at k + 16 i
+							st_blk<1>(&pub.dbuf[256 * J + e], Dv[(e & 15) + (e >> 4) * PT]);
+						}
+					}
+					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+				}
 			}
 		}
 		SPP_STAMP(7 + 6 * J, 0);
 		SPP_STAMP(8 + 6 * J, 64);
 		lds_barrier(); // LDS traffic only: the write-back stores stay in flight
+		if(HALF == 2 && pub.flag && tid == 0)
+			__hip_atomic_store(pub.flag, pub.base + J + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
 	SPP_STAMP(51, 0);
-	if(*fail)
+	if(*fail) {
+		if(pub.abort && tid == 0)
+			__hip_atomic_store(pub.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		return;
-	// R and the inverse went back block row by block row inside the loop; the carried rhs remains
+	}
+	if(HALF == 2) {
+		// ---- the inverse, after the factorization: G = R^-T (lower triangular) in the unused lower triangle of the image,
+		// by recursive doubling over the 16 x 16 tiles. With the diagonal tiles G_JJ known (the tile factorization left
+		// them in the Gd slots), a block [[G11, 0], [G21, G22]] of twice the size has G21 = -G22 (L21 G11), L21 = R12^T:
+		// two stages of independent tile products per level (M = L21 G11 into the destination tiles, then G21 from M),
+		// 4, 8, 16 tiles at the three levels: 21 k cycles, behind the last published row tile.
+		lds_barrier();
+#pragma unroll 1
+		for(int h = 1; h < NB / 16; h *= 2) { // half size of the level's blocks, in tiles
+			const int nt = 4 * h;               // tiles of this level: (8 / 2h) blocks x h x h
+			const int blk = wave / (h * h), within = wave % (h * h);
+			const int base = blk * 2 * h, I = base + h + within / h, K = base + within % h;
+			const bool mine = wave < nt;
+			double *D = T + 16 * I + (16 * K) * TS; // destination tile (I, K), I > K
+			if(mine) { // M(I, K) = sum_{Jt = K .. base+h-1} R_JI^T G_JK
+				v4f64 acc = (v4f64){0, 0, 0, 0};
+				for(int Jt = K; Jt < base + h; ++ Jt) {
+					const double *a = T + 16 * Jt + (16 * I) * TS; // R_JI: element (k, i) at a[k + i TS]
+					const v4f64 m = (Jt == K) ? tile_atb(a, 1, TS, gd_slot(K), 1, PT, lane)
+					                          : tile_atb(a, 1, TS, T + 16 * Jt + (16 * K) * TS, 1, TS, lane);
+					acc += m;
+				}
+#pragma unroll
+				for(int r = 0; r < 4; ++ r)
+					D[(l4 + 4 * r) + l15 * TS] = acc[r];
+			}
+			lds_barrier();
+			v4f64 res = (v4f64){0, 0, 0, 0};
+			if(mine) { // G(I, K) = -sum_{Jt = base+h .. I} G_IJ M(J, K); A operand element (k, i) = G_IJ[i][k]
+				for(int Jt = base + h; Jt <= I; ++ Jt) {
+					const double *b = T + 16 * Jt + (16 * K) * TS; // M(J, K)
+					const v4f64 g = (Jt == I) ? tile_atb(gd_slot(I), PT, 1, b, 1, TS, lane)
+					                          : tile_atb(T + 16 * I + (16 * Jt) * TS, TS, 1, b, 1, TS, lane);
+					res += g;
+				}
+			}
+			lds_barrier(); // every M tile of the level has been read
+			if(mine) {
+#pragma unroll
+				for(int r = 0; r < 4; ++ r)
+					D[(l4 + 4 * r) + l15 * TS] = -res[r];
+			}
+			lds_barrier();
+		}
+		// the whole inverse goes back: tinv(r, c) = G[c][r] for r < c, 1 / R_cc on the diagonal, zeros below
+		for(int e = tid; e < NB * NB; e += POTRF_THREADS) {
+			const int r = e & (NB - 1), c = e >> 7;
+			if(WT < 2 || r <= c)
+				st_blk<0>(&tinv[r + c * NB], (r == c) ? dinv[r] : ((r < c) ? T[c + r * TS] : 0.0));
+		}
+	}
+	// R and the inverse went back block row by block row inside the loop (HALF = 2: the inverse just now); the carried rhs remains
 	if(rhs_col >= 0 && tid < n_valid)
 		st_blk<WT>(&Ablk[tid + (int64_t)rhs_col * ld], yv[tid]);
 	SPP_STAMP(52, 0);

@@ -1,0 +1,286 @@
+// spp_dense_tail.h -- the tail of the dense factor (trailing matrix of at most ~20 tile rows) as ONE launch whose
+// workgroups own one 128 x 128 tile each and stream the factorization through it 16 rows at a time.
+// (included by spp_dense.hip; device code + the argument block)
+//
+// The single-stream tail of the round-2 schedule costs 42 us per step: fused [update + potrf_diag] 31, panel solve 8,
+// launch gaps 3 -- and potrf_diag, row panel and update of one step follow each other. Here
+//   * tile (i, j), i <= j, of the tail lives in the LDS / registers of workgroup (i, j) from the start of the launch
+//     until its own step i (20 tile rows = 210-230 tiles: one workgroup per CU, all resident);
+//   * the workgroup of a diagonal tile factors it with potrf_diag_body<HALF = 2> (no inverse inside the loop), which
+//     publishes row tile J of R_ii and the inverse of its 16 x 16 diagonal tile as soon as panel J is done;
+//   * the workgroups (i, j > i) of the row panel consume them as they appear: X_J = Dinv_J^T Y_J, Y_I -= R_JI^T X_J
+//     (substitution by 16-row tiles, no block inverse), publish X_J = rows 16 J .. 16 J + 15 of R(i, j);
+//   * every workgroup below, (i', j') with i' > i, applies the rank-16 update  T -= R(i, i')_J^T R(i, j')_J  to its
+//     accumulators the moment both row tiles are out -- so tile (i+1, i+1) has the whole update of step i a few
+//     microseconds after potrf_diag(i) ends, already sits in the LDS of the workgroup that factors it, and that
+//     workgroup starts at once: a step costs potrf_diag's panel loop (19 us) plus one hand-over chain, not 42 us.
+// The inverse of each diagonal block (the backward substitution wants it) is formed by the same workgroup AFTER its
+// factorization, off the chain. Hand-overs: the payload is stored write-through (agent-scope atomic stores), every storing
+// wave drains (s_waitcnt vmcnt(0)), workgroup barrier, one lane stores the counter; a consumer polls the counter with
+// one lane (relaxed, agent scope) and reads the payload with agent-scope atomic loads (L2-bypassing on gfx950) -- no
+// fences. Counters carry the epoch of the factorization in their upper bits (no clearing between factorizations).
+// Workgroups are numbered row by row: whatever a workgroup waits for is produced by a workgroup with a smaller index,
+// which never waits for a larger one -- progress does not depend on residency. Every wait is bounded (abort word).
+// Summation order per tile: steps ascending, row tiles ascending -- fixed, bit-reproducible.
+#pragma once
+#include "spp_dense_dev.h"
+
+namespace spp {
+
+struct TailArgs {
+	double *A;           // the matrix (column-major, leading dimension ld)
+	int64_t ld;
+	int64_t rows;        // pivot rows of the matrix (rows >= this are identity padding)
+	int64_t ncols;       // columns (the right-hand side column included)
+	int64_t c0;          // first row / column of the tail region
+	int have_pre;        // 1: the row panel of the step before the region (rows c0 - 128 .. c0 - 1) is complete in memory and not yet applied
+	int Tr, Tc;          // tile rows / tile columns of the region
+	int has_rhs;
+	double *tinv;        // block inverses of the region's diagonal blocks (Tr x 128 x 128)
+	double *dbuf;        // [Tr][8][256]: inverse 16 x 16 diagonal tiles as they are published
+	int *pub;            // [Tr][Tc]: (epoch << 4) | row tiles published
+	int epoch;
+	int *info, *abort;
+	long long timeout_ticks;
+	long long *trace;    // debugging (SPP_TAIL_TRACE): per tile row 8 wall-clock stamps
+};
+
+constexpr int TAIL_LDS_DOUBLES = POTRF_LDS_DOUBLES_INV2 + 16;
+
+__device__ __forceinline__ double tail_ld(const double *p)
+{
+	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(POTRF_THREADS)
+void dense_tail_kernel(const TailArgs a)
+{
+	extern __shared__ double sm[];
+	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int l15 = lane & 15, l4 = lane >> 4;
+	int *st = (int*)(sm + POTRF_LDS_DOUBLES_INV2); // st[0] = wait succeeded, st[1] = row tiles available
+	// ---- which tile
+	int ti = 0, tj = 0;
+	{
+		int rem = (int)blockIdx.x;
+		while(rem >= a.Tc - ti) {
+			rem -= a.Tc - ti;
+			++ ti;
+		}
+		tj = ti + rem;
+	}
+	const bool diag = ti == tj;
+	const int64_t i0 = a.c0 + (int64_t)NB * ti, j0 = a.c0 + (int64_t)NB * tj;
+	const int tag = a.epoch << 4;
+	auto stamp = [&](int slot) { if(a.trace && tid == 0) a.trace[ti * 8 + slot] = wall_clock64(); };
+	if(diag) stamp(0);
+	// bounded wait by one lane: counters p (and q) of this epoch at least `need`; returns how many row tiles are out
+	auto wait_pub = [&](const int *p, const int *q, const int need) -> int {
+		if(tid == 0) {
+			const long long t0 = wall_clock64();
+			int got = -1;
+			for(;;) {
+				const int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				const int w = q ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : v;
+				const int cv = ((v >> 4) == a.epoch) ? (v & 15) : 0, cw = ((w >> 4) == a.epoch) ? (w & 15) : 0;
+				const int c = cv < cw ? cv : cw;
+				if(c >= need) {
+					got = c;
+					break;
+				}
+				if(__hip_atomic_load(a.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+					break;
+				if(wall_clock64() - t0 > a.timeout_ticks) {
+					__hip_atomic_store(a.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					break;
+				}
+				__builtin_amdgcn_s_sleep(1);
+			}
+			st[1] = got;
+		}
+		lds_barrier();
+		const int got = st[1];
+		lds_barrier(); // (st is rewritten by the next wait)
+		return got;
+	};
+	// ---- the tile into accumulators: wave w holds the 16 x 16 tiles (ta, tb0 .. tb0 + 3); element (16 ta + l4 + 4 r,
+	// 16 tb + l15) of the tile in acc[t][r] (the MFMA result layout of tile_atb)
+	const int ta = wave & 7, tb0 = 4 * (wave >> 3);
+	v4f64 acc[4];
+#pragma unroll
+	for(int t = 0; t < 4; ++ t) {
+		const int64_t col = j0 + 16 * (tb0 + t) + l15;
+#pragma unroll
+		for(int r = 0; r < 4; ++ r) {
+			const int64_t row = i0 + 16 * ta + l4 + 4 * r;
+			// (columns beyond the right-hand side are padding: zero, the identity on a diagonal tile's diagonal)
+			acc[t][r] = (diag && ta > tb0 + t) ? 0.0 : ((col < a.ncols) ? a.A[row + col * a.ld] : ((diag && row == col) ? 1.0 : 0.0));
+		}
+	}
+	// ---- steps before this tile's own: T -= R(k, i)_J^T R(k, j)_J as the row tiles appear.
+	// A row tile (16 x 128, column-major) is fetched by the whole workgroup -- 16 consecutive lanes on the 128 bytes of one
+	// column, two elements per thread and tile, all loads in flight together -- into an LDS image [k + c * PT]; the MFMA
+	// operands come out of LDS. Two images per side: while row tile s is applied, row tile s + 1 -- if it is out already,
+	// i.e. whenever this workgroup lags its producers -- is on its way (a per-lane gather of the MFMA fragments straight
+	// from memory, 20 loads of 32-byte pieces per wave and row tile, took 6.4 us per row tile against the 2.3 us at
+	// which the factorization emits them).
+	{
+		const int ek = tid & 15, ec = tid >> 4; // this thread's elements: (ek, ec) and (ek, ec + 64) of a row tile
+		const int kfirst = a.have_pre ? -1 : 0, nst = 8 * (ti - kfirst);
+		double va[2], vb[2];
+		auto fetch = [&](const int sidx) {
+			const int k = kfirst + (sidx >> 3), J = sidx & 7;
+			const double *rowp = a.A + (a.c0 + (int64_t)NB * k) + 16 * J + ek;
+#pragma unroll
+			for(int h = 0; h < 2; ++ h) {
+				const int64_t ca = i0 + ec + 64 * h, cb = j0 + ec + 64 * h;
+				// (a diagonal tile uses ONE image for both sides: it must hold the right-hand side column too; the rows of the
+				// tile beyond the pivots -- identity padding, no update -- are masked when the A fragments are formed)
+				va[h] = (ca < (diag ? a.ncols : a.rows)) ? tail_ld(rowp + ca * a.ld) : 0.0;
+				vb[h] = (!diag && cb < a.ncols) ? tail_ld(rowp + cb * a.ld) : 0.0;
+			}
+		};
+		int avail = a.have_pre ? 8 : 0; // row tiles of the current step known to be out
+		bool inflight = false;
+		for(int sidx = 0; sidx < nst; ++ sidx) {
+			const int k = kfirst + (sidx >> 3), J = sidx & 7;
+			if(J == 0 && k >= 0)
+				avail = 0;
+			if(!inflight) {
+				if(J >= avail) {
+					avail = wait_pub(a.pub + k * a.Tc + ti, a.pub + k * a.Tc + tj, J + 1);
+					if(avail < 0)
+						return;
+				}
+				fetch(sidx);
+			}
+			double *sa = sm + (sidx & 1) * 2 * NB * PT, *sb = diag ? sa : sa + NB * PT; // two images per side, alternating
+#pragma unroll
+			for(int h = 0; h < 2; ++ h) {
+				sa[ek + (ec + 64 * h) * PT] = va[h];
+				if(!diag)
+					sb[ek + (ec + 64 * h) * PT] = vb[h];
+			}
+			lds_barrier();
+			// the next row tile, if it is out already (same step: the count the last wait returned says so; next step: not known)
+			inflight = (sidx + 1 < nst) && (J + 1 < 8) && (J + 1 < avail);
+			if(inflight)
+				fetch(sidx + 1);
+			double fa[4];
+			const bool row_live = i0 + 16 * ta + l15 < a.rows;
+#pragma unroll
+			for(int kk = 0; kk < 4; ++ kk)
+				fa[kk] = row_live ? -sa[(4 * kk + l4) + (16 * ta + l15) * PT] : 0.0;
+#pragma unroll
+			for(int t = 0; t < 4; ++ t) {
+				if(diag && ta > tb0 + t)
+					continue; // (below the diagonal of a diagonal tile: never used)
+				double fb[4];
+#pragma unroll
+				for(int kk = 0; kk < 4; ++ kk)
+					fb[kk] = sb[(4 * kk + l4) + (16 * (tb0 + t) + l15) * PT];
+#pragma unroll
+				for(int kk = 0; kk < 4; ++ kk)
+					acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[kk], fb[kk], acc[t], 0, 0, 0);
+			}
+		}
+		lds_barrier(); // (the images are overwritten by the tile below)
+	}
+	if(diag) stamp(1);
+	// ---- own step: the accumulators become the LDS image
+	double *T = sm;
+#pragma unroll
+	for(int t = 0; t < 4; ++ t)
+#pragma unroll
+		for(int r = 0; r < 4; ++ r)
+			T[(16 * ta + l4 + 4 * r) + (16 * (tb0 + t) + l15) * TS] = acc[t][r];
+	lds_barrier();
+	if(diag) {
+		const int64_t nv = a.rows - i0;
+		const int n_valid = (int)(nv < 0 ? 0 : (nv > NB ? NB : nv));
+		PotrfPub pb;
+		pb.flag = a.pub + ti * a.Tc + ti;
+		pb.base = tag;
+		pb.dbuf = a.dbuf + (size_t)ti * 8 * 256;
+		pb.abort = a.abort;
+		potrf_diag_body<false, 1, 2, true>(a.A + i0 + i0 * a.ld, a.ld, n_valid, (a.has_rhs && n_valid < NB) ? 1 : 0,
+			a.tinv + (size_t)ti * NB * NB, a.info, i0, sm, pb);
+		stamp(2);
+		return;
+	}
+	// ---- a tile of the row panel of step ti: substitution by 16-row tiles behind the factorization of (ti, ti)
+	double *Dv = T + NB * TS;       // Dinv_J[k][i] at k + i * PT
+	double *Rr = Dv + 16 * PT;      // row tile J of R_ii right of its diagonal tile: element (k, c) at k + c * PT, c = column - 16 (J + 1)
+	const double *Rii = a.A + i0 + i0 * a.ld;
+	int avail = 0;
+	bool inflight = false;
+	double dvr = 0, rr[2] = {0, 0}; // this thread's pieces of Dinv_J and of the row tile, fetched one row tile ahead when it is out already
+	auto fetch_panel = [&](const int J) {
+		if(tid < 256)
+			dvr = tail_ld(a.dbuf + ((size_t)ti * 8 + J) * 256 + tid);
+#pragma unroll
+		for(int h = 0; h < 2; ++ h) {
+			const int e = tid + POTRF_THREADS * h, k = e & 15, c = e >> 4;
+			if(e < 16 * (NB - 16 * (J + 1)))
+				rr[h] = tail_ld(Rii + (16 * J + k) + (int64_t)(16 * (J + 1) + c) * a.ld);
+		}
+	};
+	for(int J = 0; J < 8; ++ J) {
+		if(!inflight) {
+			if(J >= avail) {
+				avail = wait_pub(a.pub + ti * a.Tc + ti, nullptr, J + 1);
+				if(avail < 0)
+					return;
+			}
+			fetch_panel(J);
+		}
+		if(tj == ti + 1 && J == 0) stamp(3);
+		if(tj == ti + 1 && J == 7) stamp(4);
+		// stage Dinv_J and the row tile
+		if(tid < 256)
+			Dv[(tid & 15) + (tid >> 4) * PT] = dvr;
+#pragma unroll
+		for(int h = 0; h < 2; ++ h) {
+			const int e = tid + POTRF_THREADS * h;
+			if(e < 16 * (NB - 16 * (J + 1)))
+				Rr[(e & 15) + (e >> 4) * PT] = rr[h];
+		}
+		lds_barrier();
+		inflight = (J + 1 < 8) && (J + 1 < avail);
+		if(inflight)
+			fetch_panel(J + 1);
+		// X_J = Dinv_J^T Y_J: waves 0 .. 7, one column tile each; stored (write-through) as rows 16 J .. of R(ti, tj)
+		if(wave < 8) {
+			double *Y = T + 16 * J + (16 * wave) * TS;
+			const v4f64 x = tile_atb(Dv, 1, PT, Y, 1, TS, lane);
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			const int64_t col = j0 + 16 * wave + l15;
+#pragma unroll
+			for(int r = 0; r < 4; ++ r) {
+				Y[(l4 + 4 * r) + l15 * TS] = x[r];
+				if(col < a.ncols)
+					__hip_atomic_store(&a.A[(i0 + 16 * J + l4 + 4 * r) + col * a.ld], x[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+		}
+		lds_barrier();
+		// Y_I -= R_JI^T X_J for the row tiles I > J: (7 - J) x 8 tile products over the 16 waves
+		for(int q = wave; q < (7 - J) * 8; q += POTRF_THREADS / 64) {
+			const int I = J + 1 + (q >> 3), b = q & 7;
+			const v4f64 d = tile_atb(Rr + 16 * (I - J - 1) * PT, 1, PT, T + 16 * J + (16 * b) * TS, 1, TS, lane);
+			double *D = T + 16 * I + (16 * b) * TS;
+#pragma unroll
+			for(int r = 0; r < 4; ++ r)
+				D[(l4 + 4 * r) + l15 * TS] -= d[r];
+		}
+		// the row tile is out: the storing waves drain (their stores have had the update above to complete), then one counter store
+		if(wave < 8)
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		lds_barrier();
+		if(tid == 0)
+			__hip_atomic_store(a.pub + ti * a.Tc + tj, tag | (J + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if(tj == ti + 1 && J == 7) stamp(5);
+	}
+}
+
+} // namespace spp

@@ -233,6 +233,9 @@ struct DenseWork {
 	int64_t tinv_half = 0;         // > 0: that many of them are in the two-halves form the factorization leaves (completed before a solve)
 	DevBuf<double> xtmp;           // solution of the backward substitution before it replaces y
 	DevBuf<int> flags;             // per block row: epoch of the solve that last published x_b (chain kernel)
+	DevBuf<int> tail_pub;          // streamed tail of the dense factor: per tile, (epoch << 4) | row tiles published
+	DevBuf<double> tail_dinv;      // ... and the inverse 16 x 16 diagonal tiles it publishes
+	int tail_epoch = 0;
 	DevBuf<double> trsv_pay;       // hand-over pairs {value, check word} of the one-workgroup chain: x (nblk x 128) and w (nblk x 128)
 	int epoch = 0;
 	int *h_chain_err = nullptr;
