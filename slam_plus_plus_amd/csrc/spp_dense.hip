@@ -1356,7 +1356,7 @@ static bool launch_dense_tail(spp_ctx *ctx, double *d_A, int64_t ld, int64_t row
 	static int enabled = -1;
 	if(enabled < 0) {
 		const char *e = getenv("SPP_DENSE_TAIL"); // 1: the streamed tail; 0: the per-step single-stream tail of round 2
-		enabled = e ? atoi(e) : 0;
+		enabled = e ? atoi(e) : 1;
 	}
 	DenseWork &dw = ctx->dense;
 	const int64_t c1 = (k + 1) * NB;

@@ -328,8 +328,10 @@ __device__ __forceinline__ void potrf_diag_body(double *__restrict__ Ablk, int64
 	// the elimination (5 500 cycles) while the other 15 waves stream in the rest of the block (6 500 cycles).
 	// Not possible when the carried right-hand side sits inside that tile (n_valid < 16): plain order then.
 	const bool fast0 = !PRELOADED && !(rhs_col >= 0 && rhs_col < 16);
-	if(tid == 0)
-		*fail = 0;
+	if(tid == 0) {
+		fail[0] = 0;
+		fail[2] = 0; // (HALF = 2: count of the waves that have their part of a streamed row tile in memory)
+	}
 	if(fast0) {
 		if(wave == 0) {
 			double v[4];
@@ -434,8 +436,10 @@ __device__ __forceinline__ void potrf_diag_body(double *__restrict__ Ablk, int64
 				if(pub.flag) {
 					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 					lds_barrier();
-					if(tid == 0)
+					if(tid == 0) {
+						fail[2] = 3 * (J + 1); // (the count of the streaming waves, kept in step)
 						__hip_atomic_store(pub.flag, pub.base + J + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					}
 				}
 				continue;
 			}
@@ -524,10 +528,32 @@ __device__ __forceinline__ void potrf_diag_body(double *__restrict__ Ablk, int64
 				const int slot = wave - 1 - (wave >> 2);
 				const bool takes_tiles = (wave & 3) != 0;
 #else
+				static_assert(HALF != 2, "the streamed form puts its row tiles out through the waves that take no update tiles");
 				constexpr int NCW = NW - 1;
 				const int slot = wave - 1;
 				const bool takes_tiles = true;
 #endif
+				if(HALF == 2 && pub.flag && !takes_tiles) {
+					// streamed: row tile J of R is final since step B, and the three waves that take no update tiles put it out
+					// NOW -- with the inverse of its diagonal tile -- instead of all waves after their tiles: each drains its own
+					// stores, the last of the three to have done so stores the counter (an LDS count, no workgroup barrier):
+					// the row tile is visible ~1.5 us after step B instead of after the whole of step C
+					const int t3 = ((wave >> 2) - 1) * 64 + lane; // 0 .. 191
+					for(int e = t3; e < 16 * (NB - j0); e += 3 * 64) {
+						const int r = j0 + (e & 15), c = j0 + (e >> 4);
+						if(r <= c && c != rhs_col)
+							st_blk<1>(&Ablk[r + (int64_t)c * ld], T[r + c * TS]);
+					}
+					if(pub.dbuf)
+						for(int e = t3; e < 256; e += 3 * 64) // Dinv[k][i] at k + 16 i
+							st_blk<1>(&pub.dbuf[256 * J + e], Dv[(e & 15) + (e >> 4) * PT]);
+					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+					int old_cnt = 0;
+					if(lane == 0)
+						old_cnt = __hip_atomic_fetch_add(&fail[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					if(lane == 0 && old_cnt == 3 * J + 2)
+						__hip_atomic_store(pub.flag, pub.base + J + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
 				for(int q = (takes_tiles ? slot + 1 : (1 << 20)); q < nR + nG; q += 2 * NCW) { // two tiles per wave and round
 					const int q1 = q + NCW;
 					int I0, C0, I1 = 0, C1 = 0;
@@ -568,7 +594,7 @@ __device__ __forceinline__ void potrf_diag_body(double *__restrict__ Ablk, int64
 				// longer than wave 0's elimination and slowed it through the shared SIMD; three tiles per wave and round
 				// cost what two rounds of two cost (the update is bound by the MFMA pipe: one v_mfma_f64_16x16x4 per
 				// ~105 cycles and SIMD, which is also what bounds the bare-MFMA loop at 47 TFLOP/s).
-				{
+				if(!(HALF == 2 && pub.flag)) {
 					const int t15 = (wave - 1) * 64 + lane; // 0 .. 959
 					for(int e = t15; e < 16 * (NB - j0); e += (NW - 1) * 64) { // R: 16 rows x (NB - j0) columns
 						const int r = j0 + (e & 15), c = j0 + (e >> 4);
@@ -594,25 +620,11 @@ __device__ __forceinline__ void potrf_diag_body(double *__restrict__ Ablk, int64
 						s += T[(j0 + k) + ti * TS] * yv[j0 + k];
 					yv[ti] -= s;
 				}
-				if(HALF == 2 && pub.flag) {
-					// streamed: the inverse of this panel's diagonal tile goes out beside its rows (wave 15), and every storing
-					// wave drains before the barrier below -- the stores have had the rest of wave 0's elimination to complete
-					if(wave == NW - 1 && pub.dbuf) {
-#pragma unroll
-						for(int t = 0; t < 4; ++ t) {
-							const int e = lane + 64 * t; // Dinv[k][i] at k + 16 i
-							st_blk<1>(&pub.dbuf[256 * J + e], Dv[(e & 15) + (e >> 4) * PT]);
-						}
-					}
-					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-				}
 			}
 		}
 		SPP_STAMP(7 + 6 * J, 0);
 		SPP_STAMP(8 + 6 * J, 64);
 		lds_barrier(); // LDS traffic only: the write-back stores stay in flight
-		if(HALF == 2 && pub.flag && tid == 0)
-			__hip_atomic_store(pub.flag, pub.base + J + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
 	SPP_STAMP(51, 0);
 	if(*fail) {

@@ -74,6 +74,11 @@ void dense_tail_kernel(const TailArgs a)
 	const int tag = a.epoch << 4;
 	auto stamp = [&](int slot) { if(a.trace && tid == 0) a.trace[ti * 8 + slot] = wall_clock64(); };
 	if(diag) stamp(0);
+	// how many row tiles two counters say are out (0 for a counter of another epoch)
+	auto pub_count = [&](const int v, const int w) -> int {
+		const int cv = ((v >> 4) == a.epoch) ? (v & 15) : 0, cw = ((w >> 4) == a.epoch) ? (w & 15) : 0;
+		return cv < cw ? cv : cw;
+	};
 	// bounded wait by one lane: counters p (and q) of this epoch at least `need`; returns how many row tiles are out
 	auto wait_pub = [&](const int *p, const int *q, const int need) -> int {
 		if(tid == 0) {
@@ -103,19 +108,49 @@ void dense_tail_kernel(const TailArgs a)
 		lds_barrier(); // (st is rewritten by the next wait)
 		return got;
 	};
-	// ---- the tile into accumulators: wave w holds the 16 x 16 tiles (ta, tb0 .. tb0 + 3); element (16 ta + l4 + 4 r,
-	// 16 tb + l15) of the tile in acc[t][r] (the MFMA result layout of tile_atb)
-	const int ta = wave & 7, tb0 = 4 * (wave >> 3);
-	v4f64 acc[4];
+	// ---- the tile into accumulators. Wave w holds up to four 16 x 16 tiles (ra[u], cb[u]); element (16 ra + l4 + 4 r,
+	// 16 cb + l15) of the tile in acc[u][r] (the MFMA result layout of tile_atb). An off-diagonal tile: (w & 7, 4 (w >> 3) + u);
+	// a diagonal tile: the 36 tiles on and above its diagonal dealt round-robin (q = w + 16 u), nine per SIMD -- the rank-16
+	// update of a whole tile is 1 - 2 us of one CU's matrix cores, and on a diagonal tile it sits on the critical chain
+	int ra[4], cb[4];
 #pragma unroll
-	for(int t = 0; t < 4; ++ t) {
-		const int64_t col = j0 + 16 * (tb0 + t) + l15;
-#pragma unroll
-		for(int r = 0; r < 4; ++ r) {
-			const int64_t row = i0 + 16 * ta + l4 + 4 * r;
-			// (columns beyond the right-hand side are padding: zero, the identity on a diagonal tile's diagonal)
-			acc[t][r] = (diag && ta > tb0 + t) ? 0.0 : ((col < a.ncols) ? a.A[row + col * a.ld] : ((diag && row == col) ? 1.0 : 0.0));
+	for(int u = 0; u < 4; ++ u) {
+		if(!diag) {
+			ra[u] = wave & 7;
+			cb[u] = 4 * (wave >> 3) + u;
+		} else {
+			int q = wave + 16 * u, c = 0; // upper tiles enumerated column by column: column c holds c + 1 of them
+			if(q >= 36)
+				ra[u] = cb[u] = -1;
+			else {
+				while(q > c) {
+					q -= c + 1;
+					++ c;
+				}
+				ra[u] = q;
+				cb[u] = c;
+			}
 		}
+	}
+	v4f64 acc[4];
+	{
+		// through an LDS image: coalesced loads (128 consecutive rows of a column per wave pair), then every lane picks
+		// its accumulator elements
+		double *img = sm;
+#pragma unroll 4
+		for(int q = 0; q < NB * NB / POTRF_THREADS; ++ q) {
+			const int e = tid + q * POTRF_THREADS, r = e & (NB - 1), c = e >> 7;
+			const int64_t row = i0 + r, col = j0 + c;
+			// (columns beyond the right-hand side are padding: zero, the identity on a diagonal tile's diagonal)
+			img[r + c * TS] = (col < a.ncols) ? a.A[row + col * a.ld] : ((diag && row == col) ? 1.0 : 0.0);
+		}
+		lds_barrier();
+#pragma unroll
+		for(int u = 0; u < 4; ++ u)
+#pragma unroll
+			for(int r = 0; r < 4; ++ r)
+				acc[u][r] = (ra[u] < 0) ? 0.0 : img[(16 * ra[u] + l4 + 4 * r) + (16 * cb[u] + l15) * TS];
+		lds_barrier();
 	}
 	// ---- steps before this tile's own: T -= R(k, i)_J^T R(k, j)_J as the row tiles appear.
 	// A row tile (16 x 128, column-major) is fetched by the whole workgroup -- 16 consecutive lanes on the 128 bytes of one
@@ -154,6 +189,13 @@ void dense_tail_kernel(const TailArgs a)
 				}
 				fetch(sidx);
 			}
+			// a look at the counters for the NEXT row tile of this step, by one lane, without waiting: the answer travels
+			// with the barrier below. (A workgroup that keeps up only ever learns of one row tile per wait; one that lags
+			// finds the next one out already and fetches it under this one's products -- that is how it catches up.)
+			int pk = -1;
+			if(tid == 0 && k >= 0 && J + 1 < 8 && J + 1 >= avail)
+				pk = pub_count(__hip_atomic_load(a.pub + k * a.Tc + ti, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+					__hip_atomic_load(a.pub + k * a.Tc + tj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 			double *sa = sm + (sidx & 1) * 2 * NB * PT, *sb = diag ? sa : sa + NB * PT; // two images per side, alternating
 #pragma unroll
 			for(int h = 0; h < 2; ++ h) {
@@ -161,27 +203,33 @@ void dense_tail_kernel(const TailArgs a)
 				if(!diag)
 					sb[ek + (ec + 64 * h) * PT] = vb[h];
 			}
+			if(tid == 0)
+				st[2 + (sidx & 1)] = pk;
 			lds_barrier();
-			// the next row tile, if it is out already (same step: the count the last wait returned says so; next step: not known)
+			{
+				const int seen = st[2 + (sidx & 1)];
+				if(seen > avail)
+					avail = seen;
+			}
+			// the next row tile, if it is out already (same step; the next step's counters are other words)
 			inflight = (sidx + 1 < nst) && (J + 1 < 8) && (J + 1 < avail);
 			if(inflight)
 				fetch(sidx + 1);
-			double fa[4];
-			const bool row_live = i0 + 16 * ta + l15 < a.rows;
 #pragma unroll
-			for(int kk = 0; kk < 4; ++ kk)
-				fa[kk] = row_live ? -sa[(4 * kk + l4) + (16 * ta + l15) * PT] : 0.0;
+			for(int u = 0; u < 4; ++ u) {
+				if(ra[u] < 0)
+					continue;
+				// (the rows of the tile beyond the pivots are identity padding: no update)
+				const bool row_live = i0 + 16 * ra[u] + l15 < a.rows;
+				double fa[4], fb[4];
 #pragma unroll
-			for(int t = 0; t < 4; ++ t) {
-				if(diag && ta > tb0 + t)
-					continue; // (below the diagonal of a diagonal tile: never used)
-				double fb[4];
+				for(int kk = 0; kk < 4; ++ kk) {
+					fa[kk] = row_live ? -sa[(4 * kk + l4) + (16 * ra[u] + l15) * PT] : 0.0;
+					fb[kk] = sb[(4 * kk + l4) + (16 * cb[u] + l15) * PT];
+				}
 #pragma unroll
 				for(int kk = 0; kk < 4; ++ kk)
-					fb[kk] = sb[(4 * kk + l4) + (16 * (tb0 + t) + l15) * PT];
-#pragma unroll
-				for(int kk = 0; kk < 4; ++ kk)
-					acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[kk], fb[kk], acc[t], 0, 0, 0);
+					acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[kk], fb[kk], acc[u], 0, 0, 0);
 			}
 		}
 		lds_barrier(); // (the images are overwritten by the tile below)
@@ -190,10 +238,11 @@ void dense_tail_kernel(const TailArgs a)
 	// ---- own step: the accumulators become the LDS image
 	double *T = sm;
 #pragma unroll
-	for(int t = 0; t < 4; ++ t)
+	for(int u = 0; u < 4; ++ u)
 #pragma unroll
 		for(int r = 0; r < 4; ++ r)
-			T[(16 * ta + l4 + 4 * r) + (16 * (tb0 + t) + l15) * TS] = acc[t][r];
+			if(ra[u] >= 0)
+				T[(16 * ra[u] + l4 + 4 * r) + (16 * cb[u] + l15) * TS] = acc[u][r];
 	lds_barrier();
 	if(diag) {
 		const int64_t nv = a.rows - i0;
@@ -236,6 +285,11 @@ void dense_tail_kernel(const TailArgs a)
 		}
 		if(tj == ti + 1 && J == 0) stamp(3);
 		if(tj == ti + 1 && J == 7) stamp(4);
+		int pk = -1; // (a look at the counter for the next row tile, as above)
+		if(tid == 0 && J + 1 < 8 && J + 1 >= avail) {
+			const int v = __hip_atomic_load(a.pub + ti * a.Tc + ti, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			pk = pub_count(v, v);
+		}
 		// stage Dinv_J and the row tile
 		if(tid < 256)
 			Dv[(tid & 15) + (tid >> 4) * PT] = dvr;
@@ -245,7 +299,14 @@ void dense_tail_kernel(const TailArgs a)
 			if(e < 16 * (NB - 16 * (J + 1)))
 				Rr[(e & 15) + (e >> 4) * PT] = rr[h];
 		}
+		if(tid == 0)
+			st[2 + (J & 1)] = pk;
 		lds_barrier();
+		{
+			const int seen = st[2 + (J & 1)];
+			if(seen > avail)
+				avail = seen;
+		}
 		inflight = (J + 1 < 8) && (J + 1 < avail);
 		if(inflight)
 			fetch_panel(J + 1);
