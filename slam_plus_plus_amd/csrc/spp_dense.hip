@@ -1348,6 +1348,22 @@ static bool flag_schedule_usable(spp_ctx *ctx)
 	return dw.sync_state == 1;
 }
 
+static int dense_tail_rows()
+{
+	static int v = -1;
+	if(v < 0) {
+		const char *e = getenv("SPP_TAIL_ROWS"), *on = getenv("SPP_DENSE_TAIL");
+		v = (on && !atoi(on)) ? 0 : (e ? atoi(e) : 44);
+	}
+	return v;
+}
+
+// the streamed tail only takes over a full factorization (every tile row a pivot block, no identity-padded pivots)
+static bool dense_tail_applies(spp_ctx *ctx, int64_t rows, int64_t nsteps)
+{
+	return nsteps * NB >= rows && !(ctx->dense.ident_from >= 0 && ctx->dense.ident_from < rows);
+}
+
 // The streamed tail (spp_dense_tail.h): everything behind row panel k -- the update of step k, then steps k + 1 .. --
 // as one launch, when the trailing matrix is a full factorization (every tile row a pivot block) of few enough tiles
 // for one workgroup per CU. Returns false when it does not apply (the per-step schedule goes on).
@@ -1359,17 +1375,21 @@ static bool launch_dense_tail(spp_ctx *ctx, double *d_A, int64_t ld, int64_t row
 		enabled = e ? atoi(e) : 1;
 	}
 	DenseWork &dw = ctx->dense;
-	const int64_t c1 = (k + 1) * NB;
+	const int64_t c1 = (k + 1) * NB; // (k = -1: the whole factorization, no row panel in front of it)
 	if(!enabled || k + 1 >= nsteps || nsteps * NB < rows || (dw.ident_from >= 0 && dw.ident_from < rows))
 		return false;
 	const int Tr = (int)(nsteps - (k + 1)), Tc = (int)((ncols - c1 + NB - 1) / NB);
 	if(Tr < 1 || Tc < Tr || Tc > Tr + 1)
 		return false;
+	// (more tiles than CUs are fine: workgroups are dispatched row by row and leave after their own step, a workgroup that
+	// starts late finds the row tiles of the steps it missed in memory and catches up at the speed of its matrix cores)
 	const int ntile = Tr * Tc - Tr * (Tr - 1) / 2;
-	int dev = 0, ncu = 0;
-	SPP_HIP_CHECK(hipGetDevice(&dev));
-	SPP_HIP_CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-	if(ntile > ncu)
+	static int max_rows = -1;
+	if(max_rows < 0) {
+		const char *e = getenv("SPP_TAIL_ROWS"); // tile rows from which on the factorization is streamed
+		max_rows = e ? atoi(e) : 44;
+	}
+	if(Tr > max_rows)
 		return false;
 	hipStream_t s = ctx->stream;
 	static uint64_t attr_seen = 0;
@@ -1393,7 +1413,7 @@ static bool launch_dense_tail(spp_ctx *ctx, double *d_A, int64_t ld, int64_t row
 	a.rows = rows;
 	a.ncols = ncols;
 	a.c0 = c1;
-	a.have_pre = 1;
+	a.have_pre = (k >= 0) ? 1 : 0;
 	a.Tr = Tr;
 	a.Tc = Tc;
 	a.has_rhs = has_rhs ? 1 : 0;
@@ -1598,13 +1618,19 @@ static void dense_factor_steps_enqueue(spp_ctx *ctx, double *d_A, int64_t ld, in
 		flush_wait_b();
 		launch_gemm_staged<32, 32, 16, 16, 0>(s, m, ncols - r0, NB, P, ld, P, ld, d_A + r0 + r0 * ld, ld, true);
 	};
+	if(allow_fused && nsteps >= 2 && dense_tail_rows() * NB >= rows && dense_tail_applies(ctx, rows, nsteps) &&
+		launch_dense_tail(ctx, d_A, ld, rows, ncols, nsteps, -1, has_rhs)) {
+		dw.tinv_half = 0; // the whole factorization streamed: every block inverse is complete
+		SPP_HIP_CHECK(hipGetLastError());
+		return;
+	}
 	potrf_and_panel(0);
 	const int64_t single_below = 2560, single_mixed_above = 1280;
 	for(int64_t k = 0; k < nsteps; ++ k) {
 		const int64_t k0 = k * NB, c1 = k0 + NB, c2 = c1 + NB;
 		if(c1 >= ncols || rows - c1 <= 0)
 			break;
-		if(rows - c1 <= single_below) {
+		if(rows - c1 <= single_below || (allow_fused && dense_tail_rows() * NB >= rows - c1 && dense_tail_applies(ctx, rows, nsteps))) {
 			// small trailing matrix: the whole update is shorter than a cross-stream hand-off plus the tile row
 			if(bulk_pending) {
 				wait_b_now();

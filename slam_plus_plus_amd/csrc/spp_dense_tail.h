@@ -19,8 +19,8 @@
 // wave drains (s_waitcnt vmcnt(0)), workgroup barrier, one lane stores the counter; a consumer polls the counter with
 // one lane (relaxed, agent scope) and reads the payload with agent-scope atomic loads (L2-bypassing on gfx950) -- no
 // fences. Counters carry the epoch of the factorization in their upper bits (no clearing between factorizations).
-// Workgroups are numbered row by row: whatever a workgroup waits for is produced by a workgroup with a smaller index,
-// which never waits for a larger one -- progress does not depend on residency. Every wait is bounded (abort word).
+// Workgroups are numbered row by row: whatever a workgroup waits for is produced by a workgroup
+// with a smaller index, which never waits for a larger one -- progress does not depend on residency. Every wait is bounded (abort word).
 // Summation order per tile: steps ascending, row tiles ascending -- fixed, bit-reproducible.
 #pragma once
 #include "spp_dense_dev.h"
@@ -47,9 +47,20 @@ struct TailArgs {
 
 constexpr int TAIL_LDS_DOUBLES = POTRF_LDS_DOUBLES_INV2 + 16;
 
+// A published row tile is read with agent-scope atomic loads (they bypass the L2s). Plain loads would be safe as well -- a
+// 128-byte line is exactly one row tile's piece of one column, written once, write-through, before the counter that
+// announces it, and untouched by anybody but its owner before -- and would let the 20-40 workgroups that need the same
+// row tile share it through their XCD's L2; measured slower (SPP_TAIL_PLAIN_LD=1: factor 2.54 -> 2.94 ms).
+#ifndef SPP_TAIL_PLAIN_LD
+#define SPP_TAIL_PLAIN_LD 0
+#endif
 __device__ __forceinline__ double tail_ld(const double *p)
 {
+#if SPP_TAIL_PLAIN_LD
+	return *(const volatile double*)p;
+#else
 	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
 }
 
 __global__ __launch_bounds__(POTRF_THREADS)
@@ -59,7 +70,14 @@ void dense_tail_kernel(const TailArgs a)
 	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int l15 = lane & 15, l4 = lane >> 4;
 	int *st = (int*)(sm + POTRF_LDS_DOUBLES_INV2); // st[0] = wait succeeded, st[1] = row tiles available
-	// ---- which tile
+	// ---- which tile: the upper tiles enumerated row by row. Tile (i, j) needs row tiles of (k, i) and (k, j), k < i:
+	// earlier rows, smaller indices. With more tiles than CUs (the whole Venice factorization: 861) the first ~6 rows are
+	// resident at the start, a row's workgroups leave after its step and later rows move in, finding the row tiles of the
+	// steps they missed in memory (they catch up at the speed of their matrix cores: 2 us per row tile against the 3 us
+	// at which the chain emits them). Two other topological orders were measured on the whole factorization (kernel
+	// time, row by row 2.05 ms): by anti-diagonals (i + j: a deadline order for the diagonal -- but the tiles of one
+	// column then run one after the other, each redoing all its updates in one go: 2.33 ms) and column by column (the
+	// first 20 steps at 41 us each, then every late column redoes up to 35 steps of updates at once: 3.05 ms).
 	int ti = 0, tj = 0;
 	{
 		int rem = (int)blockIdx.x;
