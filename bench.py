@@ -472,7 +472,12 @@ def main():
         n_red = float(ctx.info("N_REDUCED"))
         fac_flops = n_red ** 3 / 3.0
         mfma_meas = ctx.microbench_mfma_f64(4000)
-        out["roofline"] = {"bound": "mfma", "kernel": "spp::gemm_tn_mixed_kernel (MFMA f64 16x16x4 trailing update of the dense factor: 128x128 tiles, the tail of every launch cut into 64x64 quarters)",
+        streamed = int(ctx.info("DENSE_STREAMED"))
+        dom_name = ("spp::dense_tail_kernel (the streamed dense factor: one workgroup per 128x128 tile, rank-16 MFMA f64 16x16x4 updates as the "
+                    "factorization's row tiles appear, diagonal tiles factored in LDS; %d of %d tile rows in this launch)" % (
+                        streamed, (int(ctx.info("N_REDUCED")) + 127) // 128)) if streamed > 0 and dom_n == 1 else (
+                    "spp::gemm_tn_mixed_kernel (MFMA f64 16x16x4 trailing update of the dense factor: 128x128 tiles, the tail of every launch cut into 64x64 quarters)")
+        out["roofline"] = {"bound": "mfma", "kernel": dom_name,
                            "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                            "launches_per_solve": int(dom_n), "avg_launch_ms": dom_ms / dom_n,

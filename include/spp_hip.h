@@ -113,6 +113,7 @@ int spp_set_shard(spp_ctx *ctx, int rank, int world_size);
 #define SPP_INFO_N_LEVELS       13
 #define SPP_INFO_S_LD           14 /* leading dimension of the dense S buffer (padded); 0 when S is sparse */
 #define SPP_INFO_S_NNZB         15 /* Schur: stored blocks of the reduced camera system (upper incl. diagonal) */
+#define SPP_INFO_DENSE_STREAMED 16 /* tile rows (of 128) the last dense factorization handed to the streamed launch (spp_dense_tail.h); 0: none */
 int spp_get_info(const spp_ctx *ctx, int what, int64_t *out);
 /* elimination order chosen by the analysis: order[k] = source block column eliminated k-th */
 int spp_get_ordering(const spp_ctx *ctx, int64_t *h_order);

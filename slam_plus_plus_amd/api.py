@@ -21,7 +21,7 @@ SPP_OK, SPP_NOT_POSDEF = 0, 1
 MODE_AUTO, MODE_SPARSE, MODE_SCHUR, MODE_SCHUR_SPARSE, MODE_SCHUR_MIS = 0, 1, 2, 3, 4
 FLAG_PROFILE = 1
 INFO = dict(MODE=0, N=1, NNZB=2, NVALS=3, FACTOR_NNZ=4, FACTOR_FLOPS=5, N_REDUCED=6, N_POSES=7,
-            N_LANDMARKS=8, SCHUR_PAIRS=9, N_OBS=10, SOLVE_BYTES=11, N_SUPERNODES=12, N_LEVELS=13, S_LD=14, S_NNZB=15)
+            N_LANDMARKS=8, SCHUR_PAIRS=9, N_OBS=10, SOLVE_BYTES=11, N_SUPERNODES=12, N_LEVELS=13, S_LD=14, S_NNZB=15, DENSE_STREAMED=16)
 PHASES = ["permute", "schur_inv", "schur_gemm", "schur_rhs", "factor", "trisolve", "backsubst", "assemble", "total"]
 
 # every symbol include/spp_hip.h declares (tests/test_abi.py checks the .so exports them all)

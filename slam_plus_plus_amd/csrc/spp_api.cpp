@@ -131,6 +131,8 @@ int spp_free_memory(spp_ctx *ctx)
 	ctx->dense.flags.release();
 	ctx->dense.trsv_pay.release();
 	ctx->dense.tail_pub.release();
+	ctx->dense.tail_order.release();
+	ctx->dense.tail_order_tr = ctx->dense.tail_order_tc = 0;
 	ctx->dense.tail_dinv.release();
 	ctx->dense.tail_epoch = 0;
 	ctx->dense.epoch = 0;
@@ -366,6 +368,7 @@ int spp_get_info(const spp_ctx *ctx, int what, int64_t *out)
 	case SPP_INFO_N_LEVELS: *out = ctx->sparse ? sparse_info(ctx, what) : 0; break;
 	case SPP_INFO_S_LD: *out = (ctx->mode == SPP_MODE_SCHUR && !ctx->schur.sparse_S) ? ctx->schur.ld : 0; break;
 	case SPP_INFO_S_NNZB: *out = (ctx->mode == SPP_MODE_SCHUR) ? ctx->schur.n_sblk : 0; break;
+	case SPP_INFO_DENSE_STREAMED: *out = ctx->dense.tail_rows_last; break;
 	default: return SPP_E_BADARG;
 	}
 	return SPP_OK;

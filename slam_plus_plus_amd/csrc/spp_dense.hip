@@ -1276,6 +1276,7 @@ void dense_factor_steps(spp_ctx *ctx, double *d_A, int64_t ld, int64_t n, int64_
 	int64_t nsteps, bool has_rhs)
 {
 	ensure_dense_work(ctx, nsteps);
+	ctx->dense.tail_rows_last = 0;
 	hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
 	const bool capturing = hipStreamIsCapturing(ctx->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
 	if(!capturing && la_usable(ctx, nsteps)) { // lookahead: persistent chain kernel + one bulk launch per step
@@ -1407,7 +1408,30 @@ static bool launch_dense_tail(spp_ctx *ctx, double *d_A, int64_t ld, int64_t row
 		SPP_HIP_CHECK(hipMemsetAsync(dw.tail_pub.p, 0, dw.tail_pub.cap * sizeof(int), s));
 		dw.tail_epoch = 1;
 	}
+	// Workgroup -> tile. Tile (i, j) needs row tiles of (k, i) and (k, j), k < i, so any key alpha i + beta j with alpha > 0,
+	// beta >= 0 sorts the tiles topologically (producers before consumers: progress whatever is resident). Row by row
+	// (beta = 0) the 256 CUs start on the first ~6 rows, far tiles included, and the near-diagonal tiles of the rows
+	// behind them start late; beta > 0 holds the far columns back a little in favour of those.
+	if(dw.tail_order_tr != Tr || dw.tail_order_tc != Tc) {
+		static double beta = -1;
+		if(beta < 0) {
+			const char *e = getenv("SPP_TAIL_ORDER_BETA");
+			beta = e ? atof(e) : 0.0;
+		}
+		std::vector<std::pair<double, int> > key;
+		for(int i = 0; i < Tr; ++ i)
+			for(int j = i; j < Tc; ++ j)
+				key.push_back(std::make_pair((double)i + beta * (double)j, (i << 16) | j));
+		std::stable_sort(key.begin(), key.end(), [](const std::pair<double, int> &x, const std::pair<double, int> &y) { return x.first < y.first; });
+		std::vector<int> order(key.size());
+		for(size_t q = 0; q < key.size(); ++ q)
+			order[q] = key[q].second;
+		dw.tail_order.upload(order, s);
+		dw.tail_order_tr = Tr;
+		dw.tail_order_tc = Tc;
+	}
 	TailArgs a;
+	a.order = dw.tail_order.p;
 	a.A = d_A;
 	a.ld = ld;
 	a.rows = rows;
@@ -1437,7 +1461,15 @@ static bool launch_dense_tail(spp_ctx *ctx, double *d_A, int64_t ld, int64_t row
 		SPP_HIP_CHECK(hipMemsetAsync(trace.p, 0, (size_t)Tr * 8 * sizeof(long long), s));
 		a.trace = trace.p;
 	}
+	// (profiling: this launch is the dominant kernel of the factorization; algorithmic flops = the region's
+	// factorization m^3 / 3, the update by the row panel in front of it, the right-hand side column)
+	dom_begin(ctx);
 	hipLaunchKernelGGL(dense_tail_kernel, dim3((unsigned)ntile), dim3(POTRF_THREADS), TAIL_LDS_DOUBLES * sizeof(double), s, a);
+	{
+		const double m = (double)(rows - c1);
+		dom_end(ctx, m * m * m / 3.0 + (a.have_pre ? (double)NB * m * (m + 1.0) : 0.0) + 2.0 * m * m);
+	}
+	dw.tail_rows_last = Tr;
 	SPP_HIP_CHECK(hipGetLastError());
 	if(a.trace) {
 		std::vector<long long> h((size_t)Tr * 8);

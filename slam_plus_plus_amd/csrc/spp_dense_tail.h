@@ -43,6 +43,7 @@ struct TailArgs {
 	int *info, *abort;
 	long long timeout_ticks;
 	long long *trace;    // debugging (SPP_TAIL_TRACE): per tile row 8 wall-clock stamps
+	const int *order;    // workgroup -> tile (i << 16 | j), a topological order of the tiles (see the host side)
 };
 
 constexpr int TAIL_LDS_DOUBLES = POTRF_LDS_DOUBLES_INV2 + 16;
@@ -78,15 +79,8 @@ void dense_tail_kernel(const TailArgs a)
 	// time, row by row 2.05 ms): by anti-diagonals (i + j: a deadline order for the diagonal -- but the tiles of one
 	// column then run one after the other, each redoing all its updates in one go: 2.33 ms) and column by column (the
 	// first 20 steps at 41 us each, then every late column redoes up to 35 steps of updates at once: 3.05 ms).
-	int ti = 0, tj = 0;
-	{
-		int rem = (int)blockIdx.x;
-		while(rem >= a.Tc - ti) {
-			rem -= a.Tc - ti;
-			++ ti;
-		}
-		tj = ti + rem;
-	}
+	const int ord = a.order[blockIdx.x];
+	const int ti = ord >> 16, tj = ord & 0xffff;
 	const bool diag = ti == tj;
 	const int64_t i0 = a.c0 + (int64_t)NB * ti, j0 = a.c0 + (int64_t)NB * tj;
 	const int tag = a.epoch << 4;

@@ -236,6 +236,9 @@ struct DenseWork {
 	DevBuf<int> tail_pub;          // streamed tail of the dense factor: per tile, (epoch << 4) | row tiles published
 	DevBuf<double> tail_dinv;      // ... and the inverse 16 x 16 diagonal tiles it publishes
 	int tail_epoch = 0;
+	DevBuf<int> tail_order;        // workgroup -> tile of the streamed launch, for tail_order_tr x tail_order_tc tiles
+	int tail_order_tr = 0, tail_order_tc = 0;
+	int tail_rows_last = 0;        // tile rows the last factorization streamed (diagnostics: SPP_INFO_DENSE_STREAMED)
 	DevBuf<double> trsv_pay;       // hand-over pairs {value, check word} of the one-workgroup chain: x (nblk x 128) and w (nblk x 128)
 	int epoch = 0;
 	int *h_chain_err = nullptr;

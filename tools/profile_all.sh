@@ -11,7 +11,7 @@ mkdir -p $out profiles
 export TMPDIR=/tmp
 for w in "$@"; do
 	case $w in
-		venice871) dom=gemm_tn_mixed; steps=20;;
+		venice871) dom=dense_tail_kernel; steps=20;;
 		ladybug49) dom=s_accum_kernel; steps=50;;
 		synthetic10k) dom=s_accum_kernel; steps=5;;
 		*) dom=front_dag_kernel; steps=50;;
