@@ -58,7 +58,7 @@ constexpr int TAIL_LDS_DOUBLES = POTRF_LDS_DOUBLES_INV2 + 16;
 __device__ __forceinline__ double tail_ld(const double *p)
 {
 #if SPP_TAIL_PLAIN_LD
-	return *(const volatile double*)p;
+	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // (an ordinary cached load the compiler may not move)
 #else
 	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
