@@ -89,6 +89,27 @@ def test_posv_large_sizes(hip_ctx, n):
     assert np.abs(R.T @ R - A).max() / np.abs(A).max() < 1e-13
 
 
+def test_streamed_factor_reports_a_late_non_positive_pivot(hip_ctx):
+    """the streamed factorization (spp_dense_tail.h; 24 tile rows = 300 tiles, more than the CUs hold at once): a
+    diagonal tile deep inside fails, raises the abort word, every workgroup waiting for its row tiles gives up --
+    the call returns NOT_POSDEF (reference contract: BlockMatrix.cpp:9765-9771) instead of timing out, and the next
+    factorization on the same context is unaffected"""
+    n = 3000
+    A = _spd(n, 11)
+    B = A.copy()
+    B[2500, 2500] = -1.0
+    dA = api.DeviceArray.from_host(hip_ctx, np.asfortranarray(B).ravel(order="F"))
+    st = hip_ctx.lib.spp_dense_potrf_upper(hip_ctx.h, dA.ptr, n, n)
+    assert st == api.SPP_NOT_POSDEF
+    dA.free()
+    dA = api.DeviceArray.from_host(hip_ctx, np.asfortranarray(A).ravel(order="F"))
+    st = hip_ctx._check(hip_ctx.lib.spp_dense_potrf_upper(hip_ctx.h, dA.ptr, n, n))
+    assert st == 0
+    R = np.triu(dA.download().reshape((n, n), order="F"))
+    dA.free()
+    assert np.abs(R.T @ R - A).max() / np.abs(A).max() < 1e-13
+
+
 def test_potrf_reports_not_posdef(hip_ctx):
     """reference contract: non-positive pivot -> false (BlockMatrix.cpp:9765-9771)"""
     n = 200
