@@ -13,6 +13,8 @@
 //    different (equally valid) elimination order. Delta-x parity does not depend on the order.
 
 #include "spp_internal.h"
+#include <sys/mman.h>
+#include <stdlib.h>
 #include <algorithm>
 #include <numeric>
 #include <string.h>
@@ -179,9 +181,25 @@ struct RawBuf {
 	void resize(size_t m)
 	{
 		free(p);
-		p = m ? (T*)malloc(m * sizeof(T)) : nullptr;
-		if(m && !p)
-			throw std::bad_alloc();
+		p = nullptr;
+		if(m) {
+			// big work arrays (tens of MB, written once front to back): 2 MB-aligned and offered to transparent huge pages --
+			// first touch of 260 MB in 4 KB pages is 63 000 page faults, a third of the pair-list phase
+			const size_t bytes = m * sizeof(T);
+			if(bytes >= ((size_t)8 << 20)) {
+				void *q = nullptr;
+				if(posix_memalign(&q, (size_t)2 << 20, (bytes + (((size_t)2 << 20) - 1)) & ~(((size_t)2 << 20) - 1)) == 0) {
+					p = (T*)q;
+#ifdef MADV_HUGEPAGE
+					madvise(q, bytes, MADV_HUGEPAGE);
+#endif
+				}
+			}
+			if(!p)
+				p = (T*)malloc(bytes);
+			if(!p)
+				throw std::bad_alloc();
+		}
 		n = m;
 	}
 	size_t size() const { return n; }
