@@ -70,11 +70,12 @@ def test_posv_matches_numpy(hip_ctx, n):
     assert np.linalg.norm(x - xr) / np.linalg.norm(xr) < 1e-11
 
 
-@pytest.mark.parametrize("n", [2688, 3072, 3201, 4224])
+@pytest.mark.parametrize("n", [2688, 3072, 3201, 4224, 5800])
 def test_posv_large_sizes(hip_ctx, n):
     """sizes that run the two-stream schedule with the mixed-granularity trailing update (whole 128 x 128 tiles +
     64 x 64 quarters), its rectangular right-hand-side tile column (n a multiple of 128) and the hand-over to
-    the single-stream steps"""
+    the single-stream steps; up to 44 tile rows the whole factorization is the streamed launch (spp_dense_tail.h), at
+    5800 (46 tile rows) the two-stream schedule does the first steps and hands the rest to it"""
     A = _spd(n, 7 + n)
     b = np.random.default_rng(n).standard_normal(n)
     dA = api.DeviceArray.from_host(hip_ctx, np.asfortranarray(A).ravel(order="F"))
