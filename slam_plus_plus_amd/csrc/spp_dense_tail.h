@@ -52,6 +52,9 @@ constexpr int TAIL_LDS_DOUBLES = POTRF_LDS_DOUBLES_INV2 + 16;
 // 128-byte line is exactly one row tile's piece of one column, written once, write-through, before the counter that
 // announces it, and untouched by anybody but its owner before -- and would let the 20-40 workgroups that need the same
 // row tile share it through their XCD's L2; measured slower (SPP_TAIL_PLAIN_LD=1: factor 2.54 -> 2.94 ms).
+#ifndef SPP_TAIL_MFMA444
+#define SPP_TAIL_MFMA444 0 // 1: rank-16 updates with v_mfma_f64_4x4x4_4b -- measured: factor 2.45 -> 3.27 ms (16 A fragments out of LDS per tile instead of 4)
+#endif
 #ifndef SPP_TAIL_PLAIN_LD
 #define SPP_TAIL_PLAIN_LD 0
 #endif
@@ -231,6 +234,27 @@ void dense_tail_kernel(const TailArgs a)
 			for(int u = 0; u < 4; ++ u) {
 				if(ra[u] < 0)
 					continue;
+#if SPP_TAIL_MFMA444
+				// v_mfma_f64_4x4x4_4b (four 4 x 4 x 4 blocks per instruction, one issue per 16-17 cycles against 75 for the
+				// 2048 flop of v_mfma_f64_16x16x4: 14 % more flops per cycle). With the A operand replicated over its
+				// four blocks an instruction is a (4 x 4)(4 x 16) product: strip ib of the 16 x 16 tile, k chunk kc -- and the
+				// strip lies in accumulator register ib exactly like in the 16x16x4 form (row = l4 + 4 ib, column = l15),
+				// the B fragment IS the 16x16x4 form's; only the A fragment differs: element (k = 4 kc + l4, row 4 ib + (lane & 3)).
+				double fb[4];
+#pragma unroll
+				for(int kc = 0; kc < 4; ++ kc)
+					fb[kc] = sb[(4 * kc + l4) + (16 * cb[u] + l15) * PT];
+#pragma unroll
+				for(int ib = 0; ib < 4; ++ ib) {
+					const int m = 16 * ra[u] + 4 * ib + (lane & 3);
+					const bool row_live = i0 + m < a.rows; // (rows beyond the pivots are identity padding: no update)
+#pragma unroll
+					for(int kc = 0; kc < 4; ++ kc) {
+						const double av = row_live ? -sa[(4 * kc + l4) + m * PT] : 0.0;
+						acc[u][ib] = __builtin_amdgcn_mfma_f64_4x4x4f64(av, fb[kc], acc[u][ib], 0, 0, 0);
+					}
+				}
+#else
 				// (the rows of the tile beyond the pivots are identity padding: no update)
 				const bool row_live = i0 + 16 * ra[u] + l15 < a.rows;
 				double fa[4], fb[4];
@@ -242,6 +266,7 @@ void dense_tail_kernel(const TailArgs a)
 #pragma unroll
 				for(int kk = 0; kk < 4; ++ kk)
 					acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[kk], fb[kk], acc[u], 0, 0, 0);
+#endif
 			}
 		}
 		lds_barrier(); // (the images are overwritten by the tile below)
