@@ -230,6 +230,9 @@ void dense_tail_kernel(const TailArgs a)
 			inflight = (sidx + 1 < nst) && (J + 1 < 8) && (J + 1 < avail);
 			if(inflight)
 				fetch(sidx + 1);
+#if !SPP_TAIL_MFMA444
+			double fa[4]; // (an off-diagonal tile: the four tiles of a wave share their rows -- ONE A fragment for all four)
+#endif
 #pragma unroll
 			for(int u = 0; u < 4; ++ u) {
 				if(ra[u] < 0)
@@ -255,14 +258,17 @@ void dense_tail_kernel(const TailArgs a)
 					}
 				}
 #else
-				// (the rows of the tile beyond the pivots are identity padding: no update)
-				const bool row_live = i0 + 16 * ra[u] + l15 < a.rows;
-				double fa[4], fb[4];
+				double fb[4];
+				if(u == 0 || diag) {
+					// (the rows of the tile beyond the pivots are identity padding: no update)
+					const bool row_live = i0 + 16 * ra[u] + l15 < a.rows;
 #pragma unroll
-				for(int kk = 0; kk < 4; ++ kk) {
-					fa[kk] = row_live ? -sa[(4 * kk + l4) + (16 * ra[u] + l15) * PT] : 0.0;
-					fb[kk] = sb[(4 * kk + l4) + (16 * cb[u] + l15) * PT];
+					for(int kk = 0; kk < 4; ++ kk)
+						fa[kk] = row_live ? -sa[(4 * kk + l4) + (16 * ra[u] + l15) * PT] : 0.0;
 				}
+#pragma unroll
+				for(int kk = 0; kk < 4; ++ kk)
+					fb[kk] = sb[(4 * kk + l4) + (16 * cb[u] + l15) * PT];
 #pragma unroll
 				for(int kk = 0; kk < 4; ++ kk)
 					acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[kk], fb[kk], acc[u], 0, 0, 0);
