@@ -52,9 +52,10 @@ constexpr int TAIL_LDS_DOUBLES = POTRF_LDS_DOUBLES_INV2 + 16;
 // 128-byte line is exactly one row tile's piece of one column, written once, write-through, before the counter that
 // announces it, and untouched by anybody but its owner before -- and would let the 20-40 workgroups that need the same
 // row tile share it through their XCD's L2; measured slower (SPP_TAIL_PLAIN_LD=1: factor 2.54 -> 2.94 ms).
-#ifndef SPP_TAIL_MFMA444
-#define SPP_TAIL_MFMA444 0 // 1: rank-16 updates with v_mfma_f64_4x4x4_4b -- measured: factor 2.45 -> 3.27 ms (16 A fragments out of LDS per tile instead of 4)
-#endif
+// (The rank-16 updates with v_mfma_f64_4x4x4_4b -- the A operand replicated over its four blocks makes an instruction a
+// (4 x 4)(4 x 16) product whose strip lies in accumulator register ib exactly like in the 16x16x4 form, the B fragment is
+// the same, the A fragment is element (k = 4 kc + l4, row 4 ib + (lane & 3)) -- were built, parity-green, and measured
+// slower: factor 2.45 -> 3.27 ms; the update is bound by its LDS reads, and that form needs 16 A fragments per tile.)
 #ifndef SPP_TAIL_PLAIN_LD
 #define SPP_TAIL_PLAIN_LD 0
 #endif
@@ -176,6 +177,8 @@ void dense_tail_kernel(const TailArgs a)
 	// which the factorization emits them).
 	{
 		const int ek = tid & 15, ec = tid >> 4; // this thread's elements: (ek, ec) and (ek, ec + 64) of a row tile
+		constexpr int PS = 18;                  // column stride of a row tile's LDS image (even: 16-byte aligned columns)
+		const int ekp = 4 * (ek & 3) + (ek >> 2);
 		const int kfirst = a.have_pre ? -1 : 0, nst = 8 * (ti - kfirst);
 		double va[2], vb[2];
 		auto fetch = [&](const int sidx) {
@@ -211,12 +214,15 @@ void dense_tail_kernel(const TailArgs a)
 			if(tid == 0 && k >= 0 && J + 1 < 8 && J + 1 >= avail)
 				pk = pub_count(__hip_atomic_load(a.pub + k * a.Tc + ti, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
 					__hip_atomic_load(a.pub + k * a.Tc + tj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-			double *sa = sm + (sidx & 1) * 2 * NB * PT, *sb = diag ? sa : sa + NB * PT; // two images per side, alternating
+			// image of a row tile: element (k, c) at kp(k) + c * PS with kp(k) = 4 (k & 3) + (k >> 2): the four k values a
+			// lane feeds to its four MFMAs (k = 4 kk + l4) are then consecutive -- two 16-byte LDS reads per fragment
+			// instead of four 8-byte ones (the update is bound by its LDS reads, not by the matrix cores)
+			double *sa = sm + (sidx & 1) * 2 * NB * PS, *sb = diag ? sa : sa + NB * PS; // two images per side, alternating
 #pragma unroll
 			for(int h = 0; h < 2; ++ h) {
-				sa[ek + (ec + 64 * h) * PT] = va[h];
+				sa[ekp + (ec + 64 * h) * PS] = va[h];
 				if(!diag)
-					sb[ek + (ec + 64 * h) * PT] = vb[h];
+					sb[ekp + (ec + 64 * h) * PS] = vb[h];
 			}
 			if(tid == 0)
 				st[2 + (sidx & 1)] = pk;
@@ -230,49 +236,31 @@ void dense_tail_kernel(const TailArgs a)
 			inflight = (sidx + 1 < nst) && (J + 1 < 8) && (J + 1 < avail);
 			if(inflight)
 				fetch(sidx + 1);
-#if !SPP_TAIL_MFMA444
 			double fa[4]; // (an off-diagonal tile: the four tiles of a wave share their rows -- ONE A fragment for all four)
-#endif
 #pragma unroll
 			for(int u = 0; u < 4; ++ u) {
 				if(ra[u] < 0)
 					continue;
-#if SPP_TAIL_MFMA444
-				// v_mfma_f64_4x4x4_4b (four 4 x 4 x 4 blocks per instruction, one issue per 16-17 cycles against 75 for the
-				// 2048 flop of v_mfma_f64_16x16x4: 14 % more flops per cycle). With the A operand replicated over its
-				// four blocks an instruction is a (4 x 4)(4 x 16) product: strip ib of the 16 x 16 tile, k chunk kc -- and the
-				// strip lies in accumulator register ib exactly like in the 16x16x4 form (row = l4 + 4 ib, column = l15),
-				// the B fragment IS the 16x16x4 form's; only the A fragment differs: element (k = 4 kc + l4, row 4 ib + (lane & 3)).
-				double fb[4];
-#pragma unroll
-				for(int kc = 0; kc < 4; ++ kc)
-					fb[kc] = sb[(4 * kc + l4) + (16 * cb[u] + l15) * PT];
-#pragma unroll
-				for(int ib = 0; ib < 4; ++ ib) {
-					const int m = 16 * ra[u] + 4 * ib + (lane & 3);
-					const bool row_live = i0 + m < a.rows; // (rows beyond the pivots are identity padding: no update)
-#pragma unroll
-					for(int kc = 0; kc < 4; ++ kc) {
-						const double av = row_live ? -sa[(4 * kc + l4) + m * PT] : 0.0;
-						acc[u][ib] = __builtin_amdgcn_mfma_f64_4x4x4f64(av, fb[kc], acc[u][ib], 0, 0, 0);
-					}
-				}
-#else
 				double fb[4];
 				if(u == 0 || diag) {
 					// (the rows of the tile beyond the pivots are identity padding: no update)
 					const bool row_live = i0 + 16 * ra[u] + l15 < a.rows;
-#pragma unroll
-					for(int kk = 0; kk < 4; ++ kk)
-						fa[kk] = row_live ? -sa[(4 * kk + l4) + (16 * ra[u] + l15) * PT] : 0.0;
+					const double2 a01 = *(const double2*)(sa + 4 * l4 + (16 * ra[u] + l15) * PS), a23 = *(const double2*)(sa + 4 * l4 + 2 + (16 * ra[u] + l15) * PS);
+					fa[0] = row_live ? -a01.x : 0.0;
+					fa[1] = row_live ? -a01.y : 0.0;
+					fa[2] = row_live ? -a23.x : 0.0;
+					fa[3] = row_live ? -a23.y : 0.0;
+				}
+				{
+					const double2 b01 = *(const double2*)(sb + 4 * l4 + (16 * cb[u] + l15) * PS), b23 = *(const double2*)(sb + 4 * l4 + 2 + (16 * cb[u] + l15) * PS);
+					fb[0] = b01.x;
+					fb[1] = b01.y;
+					fb[2] = b23.x;
+					fb[3] = b23.y;
 				}
 #pragma unroll
 				for(int kk = 0; kk < 4; ++ kk)
-					fb[kk] = sb[(4 * kk + l4) + (16 * cb[u] + l15) * PT];
-#pragma unroll
-				for(int kk = 0; kk < 4; ++ kk)
 					acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[kk], fb[kk], acc[u], 0, 0, 0);
-#endif
 			}
 		}
 		lds_barrier(); // (the images are overwritten by the tile below)
