@@ -466,7 +466,9 @@ def main():
                              "288 B per block product through its pair lists (bytes_touched_by_pair_lists), which the synthetic "
                              "co-visibility (observers drawn from a 209-camera window) does not let a cache absorb"}
     # ---- roofline of the dominant kernel
-    if mode == api.MODE_SCHUR and dom_n > 0 and dom_ms > 0:
+    # (a reduced system of a few tile rows -- Ladybug-49: 294 x 294 -- also goes through the streamed launch, but there the
+    # landmark elimination is what is left to price: the HBM branch below)
+    if mode == api.MODE_SCHUR and dom_n > 0 and dom_ms > 0 and ctx.info("N_REDUCED") >= 1024:
         achieved = dom_flops / (dom_ms * 1e-3) * 1e-12
         traffic, traffic_src = pmc_traffic(args.workload)
         n_red = float(ctx.info("N_REDUCED"))
