@@ -356,21 +356,44 @@ void dense_tail_kernel(const TailArgs a)
 			}
 		}
 		lds_barrier();
-		// Y_I -= R_JI^T X_J for the row tiles I > J: (7 - J) x 8 tile products over the 16 waves
-		for(int q = wave; q < (7 - J) * 8; q += POTRF_THREADS / 64) {
-			const int I = J + 1 + (q >> 3), b = q & 7;
-			const v4f64 d = tile_atb(Rr + 16 * (I - J - 1) * PT, 1, PT, T + 16 * J + (16 * b) * TS, 1, TS, lane);
-			double *D = T + 16 * I + (16 * b) * TS;
+		// Y_I -= R_JI^T X_J for the row tiles I > J. A wave always works on column tile b = wave & 7: its X_J fragment is
+		// fetched from LDS once. FIRST the two row tiles the next two substitution steps need (I = J + 1 by waves 0 .. 7,
+		// I = J + 2 by waves 8 .. 15); then the row tile goes out (the storing waves' stores have had that time; drain,
+		// barrier, one counter store); the REST of the update (I > J + 2) comes after that, in the time this workgroup would
+		// otherwise spend waiting for the factorization's next row tile -- with the whole update in front of the counter a
+		// row tile cost 3.3 us here against the 2.7 us at which they are emitted, and the lag reached 7 us by the last one
+		{
+			const int b = wave & 7;
+			double xb[4];
 #pragma unroll
-			for(int r = 0; r < 4; ++ r)
-				D[(l4 + 4 * r) + l15 * TS] -= d[r];
+			for(int kk = 0; kk < 4; ++ kk)
+				xb[kk] = T[16 * J + (4 * kk + l4) + (16 * b + l15) * TS];
+			auto row_update = [&](const int I) {
+				const double *Ra = Rr + 16 * (I - J - 1) * PT;
+				v4f64 d = (v4f64){0, 0, 0, 0};
+#pragma unroll
+				for(int kk = 0; kk < 4; ++ kk)
+					d = __builtin_amdgcn_mfma_f64_16x16x4f64(Ra[(4 * kk + l4) + l15 * PT], xb[kk], d, 0, 0, 0);
+				double *D = T + 16 * I + (16 * b) * TS;
+#pragma unroll
+				for(int r = 0; r < 4; ++ r)
+					D[(l4 + 4 * r) + l15 * TS] -= d[r];
+			};
+			{
+				const int I = J + 1 + (wave >> 3);
+				if(I < 8)
+					row_update(I);
+			}
+			// the row tile is out
+			if(wave < 8)
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			lds_barrier();
+			if(tid == 0)
+				__hip_atomic_store(a.pub + ti * a.Tc + tj, tag | (J + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			for(int I = J + 3 + (wave >> 3); I < 8; I += 2)
+				row_update(I);
+			lds_barrier(); // (the staging of the next row tile overwrites Rr)
 		}
-		// the row tile is out: the storing waves drain (their stores have had the update above to complete), then one counter store
-		if(wave < 8)
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		lds_barrier();
-		if(tid == 0)
-			__hip_atomic_store(a.pub + ti * a.Tc + tj, tag | (J + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		if(tj == ti + 1 && J == 7) stamp(5);
 	}
 }
