@@ -8,6 +8,21 @@
 #include <math.h>
 #include <algorithm>
 
+// the streamed form of the tail kernel's diagonal workgroup: no inverse in the loop, row tiles published per panel
+// (mode 1) or not (mode 0)
+__global__ __launch_bounds__(spp::POTRF_THREADS)
+void potrf_streamed_kernel(double *Ablk, int64_t ld, int n_valid, double *tinv, int *info, int *flag, double *dbuf, int publish)
+{
+	extern __shared__ double sm[];
+	spp::PotrfPub pb;
+	if(publish) {
+		pb.flag = flag;
+		pb.base = 16;
+		pb.dbuf = dbuf;
+	}
+	spp::potrf_diag_body<false, 1, 2, false>(Ablk, ld, n_valid, 0, tinv, info, 0, sm, pb);
+}
+
 int main()
 {
 	using namespace spp;
@@ -39,6 +54,31 @@ int main()
 		printf("J=%d  B %.0f  barrier %.0f  C(wave0: upd+factor) %.0f  C(wave1) %.0f  panel total %.0f\n", J,
 			d(3 + 6 * J, 4 + 6 * J), d(4 + 6 * J, 5 + 6 * J), d(5 + 6 * J, 7 + 6 * J), d(6 + 6 * J, 8 + 6 * J),
 			J < 7 ? d(3 + 6 * J, 3 + 6 * (J + 1)) : d(3 + 6 * J, 51));
+	{
+		int *dF; double *dD;
+		hipMalloc(&dF, 64); hipMalloc(&dD, 8 * 256 * 8);
+		hipFuncSetAttribute((const void*)potrf_streamed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, POTRF_LDS_DOUBLES_INV2 * (int)sizeof(double));
+		for(int publish = 0; publish < 2; ++ publish) {
+			for(int it = 0; it < 3; ++ it) {
+				hipMemcpy(dA, A.data(), n * n * 8, hipMemcpyHostToDevice);
+				hipMemset(dI, 0, 16);
+				hipLaunchKernelGGL(potrf_streamed_kernel, dim3(1), dim3(POTRF_THREADS), POTRF_LDS_DOUBLES_INV2 * sizeof(double), 0, dA, (int64_t)n, n, dT, dI, dF, dD, publish);
+				hipDeviceSynchronize();
+			}
+			long long u[64];
+			hipMemcpyFromSymbol(u, HIP_SYMBOL(spp_potrf_trace), sizeof(u));
+			auto e = [&](int a, int b) { return (double)(u[b] - u[a]); };
+			printf("streamed form (HALF = 2), publish %d: total %.0f cycles; load %.0f; loop %.0f; after the loop (inverse) %.0f\n", publish, e(0, 52), e(0, 2), e(2, 51), e(51, 52));
+			for(int J = 0; J < 8; ++ J)
+				printf("  J=%d  B %.0f  C(wave0) %.0f  C(wave1) %.0f  panel total %.0f\n", J, e(3 + 6 * J, 4 + 6 * J), e(5 + 6 * J, 7 + 6 * J), e(6 + 6 * J, 8 + 6 * J),
+					J < 7 ? e(3 + 6 * J, 3 + 6 * (J + 1)) : e(3 + 6 * J, 51));
+		}
+		// (dA / dT now hold the streamed form's R and whole inverse: the check below completes a two-halves inverse, so restore the default kernel's results)
+		hipMemcpy(dA, A.data(), n * n * 8, hipMemcpyHostToDevice);
+		hipMemset(dI, 0, 16);
+		hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(POTRF_THREADS), POTRF_LDS_DOUBLES * sizeof(double), 0, dA, (int64_t)n, n, 0, dT, dI, (int64_t)0);
+		hipDeviceSynchronize();
+	}
 	// the results of the last launch against the input: |R^T R - A| and |R Tinv - I| (upper triangles)
 	std::vector<double> R(n * n), Ti(n * n);
 	hipMemcpy(R.data(), dA, n * n * 8, hipMemcpyDeviceToHost);
