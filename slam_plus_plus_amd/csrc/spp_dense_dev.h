@@ -547,12 +547,9 @@ __device__ __forceinline__ void potrf_diag_body(double *__restrict__ Ablk, int64
 					if(pub.dbuf)
 						for(int e = t3; e < 256; e += 3 * 64) // Dinv[k][i] at k + 16 i
 							st_blk<1>(&pub.dbuf[256 * J + e], Dv[(e & 15) + (e >> 4) * PT]);
-					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-					int old_cnt = 0;
-					if(lane == 0)
-						old_cnt = __hip_atomic_fetch_add(&fail[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-					if(lane == 0 && old_cnt == 3 * J + 2)
-						__hip_atomic_store(pub.flag, pub.base + J + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					// (no wait here: a write-through store takes 2-3 us to drain, longer than wave 0's elimination of the next
+					// tile -- waiting inside the panel held its closing barrier up by up to 1 500 cycles in the first panels.
+					// The three drain and store the counter right behind that barrier: streamed_publish below)
 				}
 				for(int q = (takes_tiles ? slot + 1 : (1 << 20)); q < nR + nG; q += 2 * NCW) { // two tiles per wave and round
 					const int q1 = q + NCW;
@@ -625,6 +622,18 @@ __device__ __forceinline__ void potrf_diag_body(double *__restrict__ Ablk, int64
 		SPP_STAMP(7 + 6 * J, 0);
 		SPP_STAMP(8 + 6 * J, 64);
 		lds_barrier(); // LDS traffic only: the write-back stores stay in flight
+#if SPP_POTRF_SIMD0_IDLE
+		if(HALF == 2 && pub.flag && wave > 0 && (wave & 3) == 0) {
+			// streamed_publish: each of the three waves that put row tile J out drains its own stores; the last of them to
+			// have done so stores the counter (an LDS count, no workgroup barrier)
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			int old_cnt = 0;
+			if(lane == 0)
+				old_cnt = __hip_atomic_fetch_add(&fail[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			if(lane == 0 && old_cnt == 3 * J + 2)
+				__hip_atomic_store(pub.flag, pub.base + J + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+#endif
 	}
 	SPP_STAMP(51, 0);
 	if(*fail) {
