@@ -264,6 +264,12 @@ static_assert(POTRF_LDS_DOUBLES_INV2 * 8 <= 160 * 1024, "the diagonal-block fact
 
 // HALF = 2 streams the factorization out: after panel J the rows 16 J .. 16 J + 15 of R (stored write-through) and the
 // inverse of their diagonal tile (dbuf + 256 J, Dinv[k][i] at k + 16 i) are complete in memory and *flag = base + J + 1
+// LDS pointers of potrf_diag_body<.., .., 2> (for a caller that factors the first tile itself: first_done)
+__device__ __forceinline__ double *potrf_lds2_dv(double *sm) { return sm + DENSE_NB * SPP_POTRF_TS; }
+__device__ __forceinline__ double *potrf_lds2_gd0(double *sm) { return potrf_lds2_dv(sm) + 2 * 16 * PT; }
+__device__ __forceinline__ double *potrf_lds2_dinv(double *sm) { return potrf_lds2_dv(sm) + (2 + DENSE_NB / 16) * 16 * PT; }
+__device__ __forceinline__ int *potrf_lds2_fail(double *sm) { return (int*)(potrf_lds2_dinv(sm) + 2 * DENSE_NB); }
+
 struct PotrfPub {
 	int *flag = nullptr;
 	int base = 0;
@@ -309,8 +315,11 @@ __device__ __forceinline__ void st_blk(double *p, const double v)
 // PRELOADED: the block's upper triangle is already in the LDS image (the workgroup accumulated it there).
 template <bool COH = false, int WT = 0, int HALF = 0, bool PRELOADED = false>
 __device__ __forceinline__ void potrf_diag_body(double *__restrict__ Ablk, int64_t ld, int n_valid, int has_rhs,
-	double *__restrict__ tinv, int *__restrict__ info, int64_t k0, double *sm, const PotrfPub pub = PotrfPub())
+	double *__restrict__ tinv, int *__restrict__ info, int64_t k0, double *sm, const PotrfPub pub = PotrfPub(), const int first_done = 0)
 {
+	// first_done (PRELOADED only): the caller has factored the first 16 x 16 tile in place already (diag_tile_factor on the
+	// image, with the LDS pointers of potrf_lds2_*, *fail initialized) -- the streamed launch does that under the last
+	// updates of the tile
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	SPP_STAMP(0, 0);
 	constexpr int GD_SLOTS = (HALF == 2) ? NB / 16 : 2;
@@ -329,7 +338,8 @@ __device__ __forceinline__ void potrf_diag_body(double *__restrict__ Ablk, int64
 	// Not possible when the carried right-hand side sits inside that tile (n_valid < 16): plain order then.
 	const bool fast0 = !PRELOADED && !(rhs_col >= 0 && rhs_col < 16);
 	if(tid == 0) {
-		fail[0] = 0;
+		if(!first_done)
+			fail[0] = 0;
 		fail[2] = 0; // (HALF = 2: count of the waves that have their part of a streamed row tile in memory)
 	}
 	if(fast0) {
@@ -397,13 +407,14 @@ __device__ __forceinline__ void potrf_diag_body(double *__restrict__ Ablk, int64
 		SPP_STAMP(1, 0);
 		if(tid < NB) {
 			yv[tid] = (rhs_col >= 0 && tid < n_valid) ? T[tid + rhs_col * TS] : 0.0;
-			dinv[tid] = 1.0;
+			if(!first_done || tid >= 16)
+				dinv[tid] = 1.0;
 		}
 		__syncthreads();
 		if(rhs_col >= 0 && tid < NB)
 			T[tid + rhs_col * TS] = (tid == rhs_col) ? 1.0 : 0.0; // the rhs column becomes plain padding
 		__syncthreads();
-		if(wave == 0)
+		if(wave == 0 && !first_done)
 			diag_tile_factor<TS>(T, DvB, gd_slot(0), dinv, 0, lane, fail, info, k0);
 		__syncthreads();
 	}

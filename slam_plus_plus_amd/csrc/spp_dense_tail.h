@@ -68,6 +68,20 @@ __device__ __forceinline__ double tail_ld(const double *p)
 #endif
 }
 
+// (a function of its own: inlined into the update loop its registers add to the loop's and the loop spills)
+__device__ __noinline__ void tail_first_tile(double *sm, const v4f64 t00, const int lane, int *info, const int64_t k0)
+{
+	const int l15 = lane & 15, l4 = lane >> 4;
+#pragma unroll
+	for(int r = 0; r < 4; ++ r)
+		sm[(l4 + 4 * r) + l15 * TS] = t00[r];
+	if(lane == 0)
+		potrf_lds2_fail(sm)[0] = 0;
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	diag_tile_factor<TS>(sm, potrf_lds2_dv(sm), potrf_lds2_gd0(sm), potrf_lds2_dinv(sm), 0, lane, potrf_lds2_fail(sm), info, k0);
+}
+
 __global__ __launch_bounds__(POTRF_THREADS)
 void dense_tail_kernel(const TailArgs a)
 {
@@ -168,6 +182,7 @@ void dense_tail_kernel(const TailArgs a)
 				acc[u][r] = (ra[u] < 0) ? 0.0 : img[(16 * ra[u] + l4 + 4 * r) + (16 * cb[u] + l15) * TS];
 		lds_barrier();
 	}
+	bool pre_first = false; // the diagonal tile's first 16 x 16 tile is eliminated under its last update
 	// ---- steps before this tile's own: T -= R(k, i)_J^T R(k, j)_J as the row tiles appear.
 	// A row tile (16 x 128, column-major) is fetched by the whole workgroup -- 16 consecutive lanes on the 128 bytes of one
 	// column, two elements per thread and tile, all loads in flight together -- into an LDS image [k + c * PT]; the MFMA
@@ -194,6 +209,7 @@ void dense_tail_kernel(const TailArgs a)
 			}
 		};
 		int avail = a.have_pre ? 8 : 0; // row tiles of the current step known to be out
+		pre_first = diag && nst > 0 && (nst & 1) == 0 && a.rows - i0 >= 16; // (the last round's images are the second pair; the right-hand side column is not in the first tile)
 		bool inflight = false;
 		for(int sidx = 0; sidx < nst; ++ sidx) {
 			const int k = kfirst + (sidx >> 3), J = sidx & 7;
@@ -261,6 +277,13 @@ void dense_tail_kernel(const TailArgs a)
 #pragma unroll
 				for(int kk = 0; kk < 4; ++ kk)
 					acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[kk], fb[kk], acc[u], 0, 0, 0);
+				if(u == 0 && pre_first && sidx == nst - 1 && wave == 0) {
+					// a diagonal tile's LAST update: wave 0 owns its first 16 x 16 tile and has it complete now. It puts it
+					// where the image will have it (that part of LDS held the row-tile images of the round before: free) and
+					// eliminates it at once -- 5 500 cycles the other waves spend on their last tiles and on the image --,
+					// then takes its other two tiles
+					tail_first_tile(sm, acc[0], lane, a.info, i0);
+				}
 			}
 		}
 		lds_barrier(); // (the images are overwritten by the tile below)
@@ -272,7 +295,7 @@ void dense_tail_kernel(const TailArgs a)
 	for(int u = 0; u < 4; ++ u)
 #pragma unroll
 		for(int r = 0; r < 4; ++ r)
-			if(ra[u] >= 0)
+			if(ra[u] >= 0 && !(pre_first && wave == 0 && u == 0))
 				T[(16 * ra[u] + l4 + 4 * r) + (16 * cb[u] + l15) * TS] = acc[u][r];
 	lds_barrier();
 	if(diag) {
@@ -284,7 +307,7 @@ void dense_tail_kernel(const TailArgs a)
 		pb.dbuf = a.dbuf + (size_t)ti * 8 * 256;
 		pb.abort = a.abort;
 		potrf_diag_body<false, 1, 2, true>(a.A + i0 + i0 * a.ld, a.ld, n_valid, (a.has_rhs && n_valid < NB) ? 1 : 0,
-			a.tinv + (size_t)ti * NB * NB, a.info, i0, sm, pb);
+			a.tinv + (size_t)ti * NB * NB, a.info, i0, sm, pb, pre_first ? 1 : 0);
 		stamp(2);
 		return;
 	}
