@@ -140,7 +140,7 @@ void dense_tail_kernel(const TailArgs a)
 	};
 	// ---- the tile into accumulators. Wave w holds up to four 16 x 16 tiles (ra[u], cb[u]); element (16 ra + l4 + 4 r,
 	// 16 cb + l15) of the tile in acc[u][r] (the MFMA result layout of tile_atb). An off-diagonal tile: (w & 7, 4 (w >> 3) + u);
-	// a diagonal tile: the 36 tiles on and above its diagonal dealt round-robin (q = w + 16 u), nine per SIMD -- the rank-16
+	// a diagonal tile: the 36 tiles on and above its diagonal dealt round-robin, eight to ten per SIMD -- the rank-16
 	// update of a whole tile is 1 - 2 us of one CU's matrix cores, and on a diagonal tile it sits on the critical chain
 	int ra[4], cb[4];
 #pragma unroll
@@ -149,7 +149,9 @@ void dense_tail_kernel(const TailArgs a)
 			ra[u] = wave & 7;
 			cb[u] = 4 * (wave >> 3) + u;
 		} else {
-			int q = wave + 16 * u, c = 0; // upper tiles enumerated column by column: column c holds c + 1 of them
+			// upper tiles enumerated column by column (column c holds c + 1 of them): wave 0 owns the first one ALONE -- it
+			// eliminates it under the tile's last update --, waves 1 .. 15 share the other 35
+			int q = (wave == 0) ? (u == 0 ? 0 : 36) : wave + 15 * u, c = 0;
 			if(q >= 36)
 				ra[u] = cb[u] = -1;
 			else {
