@@ -26,17 +26,10 @@
 
 namespace spp {
 
-// ---- -(C^-1), one thread per landmark -------------------------------------------------------------
+// ---- -(C^-1) of one landmark block (m: DL x DL column-major) ------------------------------------------
 template <int DL>
-__global__ __launch_bounds__(256)
-void cinv_kernel(int64_t nl, const int64_t *__restrict__ lm_coff, const double *__restrict__ vals,
-	double *__restrict__ cinv, double *__restrict__ lfac)
+__device__ __forceinline__ void cinv_block(const double *__restrict__ m, double *o)
 {
-	const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if(l >= nl)
-		return;
-	const double *m = vals + lm_coff[l];
-	double *o = cinv + l * DL * DL;
 	if(DL == 3) {
 		// cofactor formula with ONE reciprocal, determinant expanded along column 0
 		// (what Eigen's fixed-size 3x3 inverse evaluates)
@@ -94,47 +87,77 @@ void cinv_kernel(int64_t nl, const int64_t *__restrict__ lm_coff, const double *
 			for(int j = 0; j < DL; ++ j)
 				o[i + DL * j] = -b[i][j];
 	}
-	if(lfac) {
-		// factored operand of the S accumulation: C = G G^T (Cholesky of the block itself, not of its computed inverse),
-		// F = G^-T (upper triangular), C^-1 = F F^T -- so that W U^T = -(U F)(U F)^T needs ONE packed block per observation
-		double G[DL][DL], Gi[DL][DL];
+}
+
+// factored operand of the S accumulation: C = G G^T (Cholesky of the block itself, not of its computed inverse),
+// F = G^-T (upper triangular), C^-1 = F F^T -- so that W U^T = -(U F)(U F)^T needs ONE packed block per observation.
+// F[t + DL * q] = Ginv[q][t], zero for t > q
+template <int DL>
+__device__ __forceinline__ void lfac_block(const double *__restrict__ m, double *F)
+{
+	double G[DL][DL], Gi[DL][DL];
 #pragma unroll
-		for(int j = 0; j < DL; ++ j)
+	for(int j = 0; j < DL; ++ j)
 #pragma unroll
-			for(int i = 0; i < DL; ++ i) {
-				G[i][j] = 0;
-				if(i < j)
-					continue;
-				double sum = m[i + DL * j];
-#pragma unroll
-				for(int t = 0; t < DL; ++ t)
-					if(t < j)
-						sum -= G[i][t] * G[j][t];
-				G[i][j] = (i == j) ? sqrt(sum) : sum / G[j][j];
-			}
-#pragma unroll
-		for(int j = 0; j < DL; ++ j)
-#pragma unroll
-			for(int i = 0; i < DL; ++ i) {
-				Gi[i][j] = 0;
-				if(i < j)
-					continue;
-				if(i == j) {
-					Gi[i][j] = 1.0 / G[j][j];
-					continue;
-				}
-				double sum = 0;
-#pragma unroll
-				for(int t = 0; t < DL; ++ t)
-					if(t >= j && t < i)
-						sum += G[i][t] * Gi[t][j];
-				Gi[i][j] = -sum / G[i][i];
-			}
-#pragma unroll
-		for(int q = 0; q < DL; ++ q)
+		for(int i = 0; i < DL; ++ i) {
+			G[i][j] = 0;
+			if(i < j)
+				continue;
+			double sum = m[i + DL * j];
 #pragma unroll
 			for(int t = 0; t < DL; ++ t)
-				lfac[l * DL * DL + t + DL * q] = Gi[q][t]; // F[t][q] = Ginv[q][t], zero for t > q
+				if(t < j)
+					sum -= G[i][t] * G[j][t];
+			G[i][j] = (i == j) ? sqrt(sum) : sum / G[j][j];
+		}
+#pragma unroll
+	for(int j = 0; j < DL; ++ j)
+#pragma unroll
+		for(int i = 0; i < DL; ++ i) {
+			Gi[i][j] = 0;
+			if(i < j)
+				continue;
+			if(i == j) {
+				Gi[i][j] = 1.0 / G[j][j];
+				continue;
+			}
+			double sum = 0;
+#pragma unroll
+			for(int t = 0; t < DL; ++ t)
+				if(t >= j && t < i)
+					sum += G[i][t] * Gi[t][j];
+			Gi[i][j] = -sum / G[i][i];
+		}
+#pragma unroll
+	for(int q = 0; q < DL; ++ q)
+#pragma unroll
+		for(int t = 0; t < DL; ++ t)
+			F[t + DL * q] = Gi[q][t];
+}
+
+// ---- -(C^-1) (and F), one thread per landmark. With the factored accumulation and small landmark blocks (DL <= 3) this
+// kernel is NOT launched: obs_fact_kernel forms F and backsubst_lm_kernel forms -(C^-1) from the block itself, where they
+// are used (72 bytes read either way; 144 bytes per landmark written and read back, and a launch, less)
+template <int DL>
+__global__ __launch_bounds__(256)
+void cinv_kernel(int64_t nl, const int64_t *__restrict__ lm_coff, const double *__restrict__ vals,
+	double *__restrict__ cinv, double *__restrict__ lfac)
+{
+	const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if(l >= nl)
+		return;
+	const double *m = vals + lm_coff[l];
+	double o[DL * DL];
+	cinv_block<DL>(m, o);
+#pragma unroll
+	for(int e = 0; e < DL * DL; ++ e)
+		cinv[l * DL * DL + e] = o[e];
+	if(lfac) {
+		double F[DL * DL];
+		lfac_block<DL>(m, F);
+#pragma unroll
+		for(int e = 0; e < DL * DL; ++ e)
+			lfac[l * DL * DL + e] = F[e];
 	}
 }
 
@@ -252,7 +275,7 @@ template <int DP, int DL>
 __global__ __launch_bounds__(256)
 void obs_fact_kernel(int64_t no, const int32_t *__restrict__ obs_lm, const int64_t *__restrict__ obs_off,
 	const int64_t *__restrict__ lm_rbase, const double *__restrict__ vals, const double *__restrict__ rhs,
-	const double *__restrict__ lfac, const int32_t *__restrict__ obs_wpos, double *__restrict__ Vm, double *__restrict__ Vs,
+	const double *__restrict__ lfac, const int64_t *__restrict__ lm_coff, const int32_t *__restrict__ obs_wpos, double *__restrict__ Vm, double *__restrict__ Vs,
 	double *__restrict__ xw)
 {
 	constexpr int BLK = DP * DL, ST = BLK | 1, IL = VSplit<BLK>::IL, SIDE = VSplit<BLK>::SIDE;
@@ -276,9 +299,12 @@ void obs_fact_kernel(int64_t no, const int32_t *__restrict__ obs_lm, const int64
 			U[e] = 0;
 	}
 	double F[DL * DL], lv[DL], tv[DL];
+	if(lfac) {
 #pragma unroll
-	for(int e = 0; e < DL * DL; ++ e)
-		F[e] = lfac[(int64_t)l * DL * DL + e];
+		for(int e = 0; e < DL * DL; ++ e)
+			F[e] = lfac[(int64_t)l * DL * DL + e];
+	} else
+		lfac_block<DL>(vals + lm_coff[l], F); // (the observers of a landmark are neighbouring lanes: its block comes out of the cache)
 #pragma unroll
 	for(int q = 0; q < DL; ++ q)
 		lv[q] = active ? rhs[lm_rbase[l] + q] : 0.0;
@@ -761,7 +787,8 @@ void backsubst_obs_kernel(int64_t no, const int32_t *__restrict__ obs_pose, cons
 template <int DL>
 __global__ __launch_bounds__(256)
 void backsubst_lm_kernel(int64_t nl, const int32_t *__restrict__ lm_ptr, const int64_t *__restrict__ lm_rbase,
-	const double *__restrict__ tq, const double *__restrict__ cinv, double *__restrict__ rhs)
+	const double *__restrict__ tq, const double *__restrict__ cinv, const int64_t *__restrict__ lm_coff, const double *__restrict__ vals,
+	double *__restrict__ rhs)
 {
 	const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if(l >= nl)
@@ -776,7 +803,13 @@ void backsubst_lm_kernel(int64_t nl, const int32_t *__restrict__ lm_ptr, const i
 		for(int q = 0; q < DL; ++ q)
 			t[q] += tq[(int64_t)a * DL + q];
 	}
-	const double *Ci = cinv + l * DL * DL;
+	double Ci[DL * DL];
+	if(cinv) {
+#pragma unroll
+		for(int e = 0; e < DL * DL; ++ e)
+			Ci[e] = cinv[l * DL * DL + e];
+	} else
+		cinv_block<DL>(vals + lm_coff[l], Ci);
 #pragma unroll
 	for(int q = 0; q < DL; ++ q) {
 		double sum = 0;
@@ -817,12 +850,14 @@ static void schur_form_t(spp_ctx *ctx, const double *d_vals, const double *d_rhs
 		SPP_HIP_CHECK(hipMemsetAsync(S, 0, (size_t)schur_buffer_doubles(ctx) * sizeof(double), s));
 	constexpr int VIL = VSplit<DP * DL>::IL;
 	double *Vm = sp.W.p, *Vs = sp.W.p + sp.no * VIL; // factored form: in-line rows, then the side array, in the one buffer W
-	if(sp.nl)
+	const bool onfly = sp.factored && DL <= 3; // F and -(C^-1) formed where they are used: no cinv_kernel
+	if(sp.nl && !onfly)
 		hipLaunchKernelGGL((cinv_kernel<DL>), dim3((unsigned)((sp.nl + 255) / 256)), dim3(256), 0, s,
 			sp.nl, sp.lm_coff.p, d_vals, sp.cinv.p, sp.factored ? sp.lfac.p : nullptr);
 	if(sp.no && sp.factored)
 		hipLaunchKernelGGL((obs_fact_kernel<DP, DL>), dim3((unsigned)((sp.no + 255) / 256)), dim3(256), 0, s,
-			sp.no, sp.obs_lm.p, sp.obs_off.p, sp.lm_rbase.p, d_vals, d_rhs, sp.lfac.p, sp.obs_wpos.p, Vm, Vs, sp.xw.p);
+			sp.no, sp.obs_lm.p, sp.obs_off.p, sp.lm_rbase.p, d_vals, d_rhs, onfly ? (const double*)nullptr : (const double*)sp.lfac.p, sp.lm_coff.p,
+			sp.obs_wpos.p, Vm, Vs, sp.xw.p);
 	else if(sp.no)
 		hipLaunchKernelGGL((obs_kernel<DP, DL>), dim3((unsigned)((sp.no + 255) / 256)), dim3(256), 0, s,
 			sp.no, sp.obs_lm.p, sp.obs_off.p, sp.lm_rbase.p, d_vals, d_rhs, sp.cinv.p, sp.obs_wpos.p, sp.W.p, sp.Up.p, sp.xw.p, sp.u_landmark_major ? 1 : 0);
@@ -894,7 +929,7 @@ static int schur_finish_t(spp_ctx *ctx, const double *d_vals, double *S, double 
 			sp.no, sp.obs_pose.p, sp.obs_off.p, d_vals, xcol, sp.xw.p);
 	if(sp.nl)
 		hipLaunchKernelGGL((backsubst_lm_kernel<DL>), dim3((unsigned)((sp.nl + 255) / 256)), dim3(256), 0, s,
-			sp.nl, sp.lm_ptr.p, sp.lm_rbase.p, sp.xw.p, sp.cinv.p, d_rhs);
+			sp.nl, sp.lm_ptr.p, sp.lm_rbase.p, sp.xw.p, (sp.factored && DL <= 3) ? (const double*)nullptr : (const double*)sp.cinv.p, sp.lm_coff.p, d_vals, d_rhs);
 	if(sp.nc)
 		hipLaunchKernelGGL((scatter_dx_kernel<DP>), dim3((unsigned)((sp.nc * DP + 255) / 256)), dim3(256), 0, s,
 			sp.nc, sp.pose_rbase.p, xcol, d_rhs);
