@@ -130,6 +130,7 @@ int spp_free_memory(spp_ctx *ctx)
 	ctx->geom_partial.release();
 	ctx->dense.flags.release();
 	ctx->dense.trsv_pay.release();
+	ctx->dense.trsv_m.release();
 	ctx->dense.tail_pub.release();
 	ctx->dense.tail_order.release();
 	ctx->dense.tail_order_tr = ctx->dense.tail_order_tc = 0;

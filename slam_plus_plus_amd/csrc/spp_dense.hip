@@ -827,10 +827,13 @@ __device__ __forceinline__ void tile_dot(double2 &a, const TileRegs<NW> &t, cons
 }
 
 // NW waves (8: measured 140 us on the Venice system, 4 waves 194 us, 16 waves 142 us)
-template <int NW>
+// MFORM: the chain applies ONE precomputed tile per hop, x_b = u_b - M_b x_{b+1} with M_b = Tinv_b R_{b, b+1}
+// (trsv_m_kernel) and u_b = Tinv_b w_b formed by the helper -- 128 KB to fetch per hop instead of 208, one product and two
+// barriers instead of two and four, and two hops of prefetch fit the registers.
+template <int NW, bool MFORM>
 __global__ __launch_bounds__(64 * NW)
 void trsv_back_chain2_kernel(const double *__restrict__ R, int64_t ld, int64_t n, int nblk,
-	const double *__restrict__ tinv_all, double *y, TrsvPay *xpay, TrsvPay *wpay, unsigned long long K, int *err)
+	const double *__restrict__ tinv_all, const double *__restrict__ mbuf, double *y, TrsvPay *xpay, TrsvPay *wpay, unsigned long long K, int *err)
 {
 	__shared__ double xs[2][NB];   // chain: x_b in xs[b & 1] ; helper: xs[0 / 1] = the x_k being applied
 	__shared__ double zs[NB];
@@ -852,6 +855,9 @@ void trsv_back_chain2_kernel(const double *__restrict__ R, int64_t ld, int64_t n
 		const int b = nblk - (int)blockIdx.x;
 		const int64_t r0 = (int64_t)NB * b;
 		TileRegs<NW> ra, rb; // the tile being applied and the one after it (static slots: no indexed register arrays)
+		TileRegs<NW> tvh;    // MFORM: this block row's inverse diagonal block
+		if(MFORM)
+			tile_fetch<true, NW>(tvh, tinv_all + (size_t)b * NB * NB, NB, lane, wave);
 		const int klast = b + L + 1; // tiles k = nblk - 1 .. klast
 		double2 acc = make_double2(0, 0);
 		const double yb = (tid < NB && r0 + tid < n) ? y[r0 + tid] : 0.0; // (fetched now: not behind the last x_k)
@@ -911,8 +917,79 @@ void trsv_back_chain2_kernel(const double *__restrict__ R, int64_t ld, int64_t n
 			return;
 		*(double2*)&part[wave][2 * lane] = acc;
 		lds_barrier();
+		if(!MFORM) {
+			if(tid < NB)
+				pay_store(wpay + (size_t)b * NB + tid, yb + part_sum(tid), K);
+			return;
+		}
+		// u_b = Tinv_b w_b
 		if(tid < NB)
-			pay_store(wpay + (size_t)b * NB + tid, yb + part_sum(tid), K);
+			zs[tid] = yb + part_sum(tid);
+		lds_barrier();
+		{
+			double2 s2 = make_double2(0, 0);
+			tile_dot<NW>(s2, tvh, zs, wave, (int)((n - r0 < NB) ? (n - r0) : NB));
+			*(double2*)&part[wave][2 * lane] = s2;
+		}
+		lds_barrier();
+		if(tid < NB)
+			pay_store(wpay + (size_t)b * NB + tid, part_sum(tid), K);
+		return;
+	}
+	if(MFORM) {
+		// ---- the chain, M form: two register slots for the tiles M_b, fetched two hops ahead
+		TileRegs<NW> ma, mb2;
+		double uv = 0;
+		unsigned long long uc = 0;
+		auto ask_u = [&](int b, double &v, unsigned long long &c) {
+			const TrsvPay *p = wpay + (size_t)b * NB + tid;
+			v = __hip_atomic_load(&p->v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			c = __hip_atomic_load(&p->c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		};
+		auto fetch_m = [&](int b, TileRegs<NW> &t) {
+			if(b >= 0 && b + 1 < nblk)
+				tile_fetch<false, NW>(t, mbuf + (size_t)b * NB * NB, NB, lane, wave);
+		};
+		auto hop = [&](const int b, TileRegs<NW> &t) {
+			const int64_t r0 = (int64_t)NB * b;
+			{
+				double2 s2 = make_double2(0, 0);
+				if(b + 1 < nblk)
+					tile_dot<NW>(s2, t, xs[(b + 1) & 1], wave, NB); // (the columns of M_b beyond the next block's pivots are zero)
+				*(double2*)&part[wave][2 * lane] = s2;
+			}
+			asm volatile("" ::: "memory");
+			__builtin_amdgcn_sched_barrier(0);
+			fetch_m(b - 2, t);
+			lds_barrier();
+			if(tid < NB) {
+				int spins = 0;
+				while(((unsigned long long)__double_as_longlong(uv) ^ uc) != K && spins < SPIN_MAX) {
+					__builtin_amdgcn_s_sleep(1);
+					ask_u(b, uv, uc);
+					++ spins;
+				}
+				if(spins >= SPIN_MAX)
+					*err = 1;
+				const double xr = uv - part_sum(tid);
+				xs[b & 1][tid] = xr;
+				pay_store(xpay + (size_t)b * NB + tid, xr, K);
+				if(r0 + tid < n)
+					y[r0 + tid] = xr;
+				if(b > 0)
+					ask_u(b - 1, uv, uc);
+			}
+			lds_barrier();
+		};
+		fetch_m(nblk - 2, mb2);
+		if(tid < NB)
+			ask_u(nblk - 1, uv, uc);
+		// hop b uses slot ((nblk - 1 - b) & 1): the last block row has no tile; then mb2, ma, mb2, ..
+		for(int b = nblk - 1; b >= 0; b -= 2) {
+			hop(b, ma);      // (b = nblk - 1: no product; refills ma with the tile of hop b - 2)
+			if(b >= 1)
+				hop(b - 1, mb2);
+		}
 		return;
 	}
 	// ---- the chain. Threads 0 .. 127 own row tid of the current block for the hand-overs (w in, x out).
@@ -993,6 +1070,56 @@ void trsv_back_chain2_kernel(const double *__restrict__ R, int64_t ld, int64_t n
 		ask_w(nblk - 1, wv, wc);
 	for(int b = nblk - 1; b >= 0; -- b)
 		hop(b, t1a, tva);
+}
+
+// M_b = Tinv_b R_{b, b+1} for the M form of the backward substitution: workgroup (b, s) forms the 16 columns 16 s .. of M_b,
+// one 16 x 16 tile per wave (8 waves), Tinv_b's upper triangle and the 128 x 16 slab of R staged in LDS. The columns of the
+// last block beyond its pivots (identity padding / the right-hand side column) come out as zeros.
+constexpr int TRSVM_LDS_DOUBLES = NB * TS + 16 * TS;
+__global__ __launch_bounds__(1024)
+void trsv_m_kernel(const double *__restrict__ R, int64_t ld, int64_t n, const double *__restrict__ tinv_all, double *__restrict__ mbuf)
+{
+	extern __shared__ double sm[];
+	double *Ti = sm, *Xs = sm + NB * TS; // Tinv_b[i][k] at i + k * TS ; X[k][j] at k + j * TS (16 columns)
+	const int b = blockIdx.x, sl = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+	const double *tv = tinv_all + (size_t)b * NB * NB;
+	// 16-byte pieces of the upper tile triangle (rows 2 p, 2 p + 1 of column k)
+	for(int e = tid; e < NB * NB / 2; e += 1024) {
+		const int i = (e & (NB / 2 - 1)) * 2, k = e >> 6;
+		if((i >> 4) <= (k >> 4)) {
+			const double2 v = *(const double2*)(tv + i + (size_t)k * NB);
+			Ti[i + k * TS] = (i <= k) ? v.x : 0.0; // (only the upper triangle of a block inverse is defined)
+			Ti[i + 1 + k * TS] = (i + 1 <= k) ? v.y : 0.0;
+		}
+	}
+	const int64_t c0 = (int64_t)NB * (b + 1) + 16 * sl;
+	for(int e = tid; e < NB * 16; e += 1024) {
+		const int k = e & (NB - 1), j = e >> 7;
+		Xs[k + j * TS] = (c0 + j < n) ? R[(int64_t)NB * b + k + (c0 + j) * ld] : 0.0;
+	}
+	__syncthreads();
+	// tile (it, sl) by two waves: the even and the odd k tiles of it .. 7
+	const int it = wave & 7, half = wave >> 3;
+	v4f64 acc = (v4f64){0, 0, 0, 0};
+	for(int kt = it + half; kt < NB / 16; kt += 2) {
+		const v4f64 m = tile_atb(Ti + 16 * it + 16 * kt * TS, TS, 1, Xs + 16 * kt, 1, TS, lane); // sum_k Tinv[16 it + i][16 kt + k] X[16 kt + k][j]
+		acc += m;
+	}
+	// (the odd half's partial tile goes through a tile of the image's unused lower triangle: (7, it), it < 7; tile row 7
+	// has no odd half)
+	double *Pp = Ti + 16 * 7 + (16 * it) * TS;
+	if(half && it < 7) {
+#pragma unroll
+		for(int r = 0; r < 4; ++ r)
+			Pp[(l4 + 4 * r) + l15 * TS] = acc[r];
+	}
+	__syncthreads();
+	if(!half) {
+		double *M = mbuf + (size_t)b * NB * NB;
+#pragma unroll
+		for(int r = 0; r < 4; ++ r)
+			M[(16 * it + l4 + 4 * r) + (size_t)(16 * sl + l15) * NB] = acc[r] + (it < 7 ? Pp[(l4 + 4 * r) + l15 * TS] : 0.0);
+	}
 }
 
 __global__ void set_info_kernel(int *info) { info[0] = 0; info[1] = 0; }
@@ -1842,8 +1969,23 @@ void dense_potrs_upper(spp_ctx *ctx, const double *d_R, int64_t n, int64_t ld, d
 		// the check constant of this solve: odd multiples of a 64-bit odd constant are distinct and non-zero for 2^63 solves
 		const unsigned long long K = (2ull * (unsigned long long)(unsigned)dw.epoch + 1ull) * 0x9E3779B97F4A7C15ull;
 		TrsvPay *xpay = (TrsvPay*)dw.trsv_pay.p, *wpay = xpay + (size_t)nblk * NB;
-		hipLaunchKernelGGL((trsv_back_chain2_kernel<8>), dim3((unsigned)nblk + 1), dim3(512), 0, s,
-			d_R, ld, n, (int)nblk, dw.tinv_all.p, d_b, xpay, wpay, K, dw.info.p + 1);
+		static int mform = -1;
+		if(mform < 0) {
+			const char *e = getenv("SPP_TRSV_MFORM"); // 0: the chain applies R_{b, b+1} and Tinv_b itself (two tiles per hop)
+			mform = e ? atoi(e) : 1;
+		}
+		if(mform) {
+			if(dw.trsv_m.cap < (size_t)nblk * NB * NB)
+				dw.trsv_m.reserve((size_t)nblk * NB * NB);
+			static uint64_t attr_seen = 0;
+			if(first_on_this_device(attr_seen))
+				SPP_HIP_CHECK(hipFuncSetAttribute((const void*)trsv_m_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TRSVM_LDS_DOUBLES * (int)sizeof(double)));
+			hipLaunchKernelGGL(trsv_m_kernel, dim3((unsigned)nblk - 1, 8), dim3(1024), TRSVM_LDS_DOUBLES * sizeof(double), s, d_R, ld, n, dw.tinv_all.p, dw.trsv_m.p);
+			hipLaunchKernelGGL((trsv_back_chain2_kernel<8, true>), dim3((unsigned)nblk + 1), dim3(512), 0, s,
+				d_R, ld, n, (int)nblk, dw.tinv_all.p, dw.trsv_m.p, d_b, xpay, wpay, K, dw.info.p + 1);
+		} else
+			hipLaunchKernelGGL((trsv_back_chain2_kernel<8, false>), dim3((unsigned)nblk + 1), dim3(512), 0, s,
+				d_R, ld, n, (int)nblk, dw.tinv_all.p, (const double*)nullptr, d_b, xpay, wpay, K, dw.info.p + 1);
 		SPP_HIP_CHECK(hipGetLastError());
 		SPP_HIP_CHECK(hipMemcpyAsync(dw.h_chain_err, dw.info.p + 1, sizeof(int), hipMemcpyDeviceToHost, s));
 		return;

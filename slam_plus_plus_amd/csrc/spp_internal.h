@@ -239,6 +239,7 @@ struct DenseWork {
 	DevBuf<int> tail_order;        // workgroup -> tile of the streamed launch, for tail_order_tr x tail_order_tc tiles
 	int tail_order_tr = 0, tail_order_tc = 0;
 	int tail_rows_last = 0;        // tile rows the last factorization streamed (diagnostics: SPP_INFO_DENSE_STREAMED)
+	DevBuf<double> trsv_m;         // M_b = Tinv_b R_{b, b+1} per block row (M form of the backward substitution)
 	DevBuf<double> trsv_pay;       // hand-over pairs {value, check word} of the one-workgroup chain: x (nblk x 128) and w (nblk x 128)
 	int epoch = 0;
 	int *h_chain_err = nullptr;
