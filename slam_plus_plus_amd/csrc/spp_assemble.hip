@@ -94,8 +94,10 @@ void assemble_analyze(spp_ctx *ctx, int64_t nv, const int32_t *dim, int64_t ne, 
 	// a handful per landmark column -- by insertion, longer runs by std::stable_sort (a comparison sort of all the
 	// edges was most of this function on a Venice-sized graph)
 	std::vector<int64_t> eorder(ne);
+	std::vector<int64_t> cstart(nv + 1, 0); // edges of column c: eorder[cstart[c] .. cstart[c + 1])
+	const int nt = plan_threads(ne);
+	std::vector<int64_t> ccut; // ranges of columns with about equal numbers of edges (+ 1 per column)
 	{
-		std::vector<int64_t> cstart(nv + 1, 0);
 		for(int64_t e = 0; e < ne; ++ e)
 			++ cstart[key[e].first + 1];
 		for(int64_t c = 0; c < nv; ++ c)
@@ -103,7 +105,14 @@ void assemble_analyze(spp_ctx *ctx, int64_t nv, const int32_t *dim, int64_t ne, 
 		std::vector<int64_t> fill(cstart.begin(), cstart.end() - 1);
 		for(int64_t e = 0; e < ne; ++ e)
 			eorder[fill[key[e].first] ++] = e;
-		for(int64_t c = 0; c < nv; ++ c) {
+		{
+			std::vector<int64_t> w(nv + 1);
+			for(int64_t c = 0; c <= nv; ++ c)
+				w[c] = cstart[c] + c;
+			balanced_cuts(w, nt, ccut);
+		}
+		run_threads(nt, [&](int t) {
+		for(int64_t c = ccut[t]; c < ccut[t + 1]; ++ c) {
 			const int64_t b = cstart[c], n = cstart[c + 1] - b;
 			if(n <= 1)
 				continue;
@@ -119,6 +128,7 @@ void assemble_analyze(spp_ctx *ctx, int64_t nv, const int32_t *dim, int64_t ne, 
 				eorder[b + j] = x;
 			}
 		}
+		});
 	}
 	clk.lap("edges sorted by block");
 	Structure &st = ap->st;
@@ -129,38 +139,60 @@ void assemble_analyze(spp_ctx *ctx, int64_t nv, const int32_t *dim, int64_t ne, 
 	for(int64_t v = 0; v < nv; ++ v)
 		st.base[v + 1] = st.base[v] + dim[v];
 	st.n = st.base[nv];
+	// Columns are independent once the edges are in block order: a first pass counts the blocks and values of every column
+	// (ranges of columns on host threads), a serial prefix gives every column its place, a second pass writes.
 	st.col_ptr.assign(nv + 1, 0);
-	std::vector<int32_t> ob_ptr(1, 0), ob_edge;
-	std::vector<int64_t> ob_off, v_doff(nv);
-	ob_edge.reserve(ne);
-	ob_ptr.reserve(ne + 1);
-	ob_off.reserve(ne);
-	st.row_idx.reserve(ne + nv);
-	st.blk_off.reserve(ne + nv);
-	int64_t off = 0, q = 0;
-	for(int64_t c = 0; c < nv; ++ c) {
-		st.col_ptr[c] = (int64_t)st.row_idx.size();
-		while(q < ne && key[eorder[q]].first == c) {
-			const int64_t r = key[eorder[q]].second;
-			st.row_idx.push_back(r);
-			st.blk_off.push_back(off);
-			ob_off.push_back(off);
-			off += (int64_t)dim[r] * dim[c];
-			while(q < ne && key[eorder[q]].first == c && key[eorder[q]].second == r) {
-				const int64_t e = eorder[q]; // stable sort: edges of one block stay in edge order
-				ob_edge.push_back((int32_t)e | (v0[e] > v1[e] ? (int32_t)0x80000000 : 0));
-				++ q;
+	std::vector<int64_t> v_doff(nv), c_ob(nv + 1, 0), c_off(nv + 1, 0); // per column: first off-diagonal block, first value
+	run_threads(nt, [&](int t) {
+		for(int64_t c = ccut[t]; c < ccut[t + 1]; ++ c) {
+			int64_t nblk = 0, nval = 0, rprev = -1;
+			for(int64_t q = cstart[c]; q < cstart[c + 1]; ++ q) {
+				const int64_t r = key[eorder[q]].second;
+				if(r != rprev) {
+					++ nblk;
+					nval += (int64_t)dim[r] * dim[c];
+					rprev = r;
+				}
 			}
-			ob_ptr.push_back((int32_t)ob_edge.size());
+			c_ob[c + 1] = nblk;
+			c_off[c + 1] = nval + (int64_t)dim[c] * dim[c];
 		}
-		st.row_idx.push_back(c);
-		st.blk_off.push_back(off);
-		v_doff[c] = off;
-		off += (int64_t)dim[c] * dim[c];
+	});
+	for(int64_t c = 0; c < nv; ++ c) {
+		st.col_ptr[c + 1] = st.col_ptr[c] + c_ob[c + 1] + 1;
+		c_ob[c + 1] += c_ob[c];
+		c_off[c + 1] += c_off[c];
 	}
-	st.col_ptr[nv] = (int64_t)st.row_idx.size();
 	st.nnzb = st.col_ptr[nv];
-	st.nvals = off;
+	st.nvals = c_off[nv];
+	const int64_t n_ob = c_ob[nv];
+	std::vector<int32_t> ob_ptr(n_ob + 1), ob_edge(ne);
+	std::vector<int64_t> ob_off(n_ob);
+	ob_ptr[0] = 0;
+	st.row_idx.resize(st.nnzb);
+	st.blk_off.resize(st.nnzb);
+	run_threads(nt, [&](int t) {
+		for(int64_t c = ccut[t]; c < ccut[t + 1]; ++ c) {
+			int64_t p = st.col_ptr[c], k = c_ob[c], off = c_off[c], q = cstart[c];
+			const int64_t qe = cstart[c + 1];
+			while(q < qe) {
+				const int64_t r = key[eorder[q]].second;
+				st.row_idx[p] = r;
+				st.blk_off[p] = off;
+				++ p;
+				ob_off[k] = off;
+				off += (int64_t)dim[r] * dim[c];
+				for(; q < qe && key[eorder[q]].second == r; ++ q) {
+					const int64_t e = eorder[q]; // stable sort: edges of one block stay in edge order
+					ob_edge[q] = (int32_t)e | (v0[e] > v1[e] ? (int32_t)0x80000000 : 0);
+				}
+				ob_ptr[++ k] = (int32_t)q;
+			}
+			st.row_idx[p] = c;
+			st.blk_off[p] = off;
+			v_doff[c] = off;
+		}
+	});
 	ap->n_ob = (int64_t)ob_off.size();
 	clk.lap("Lambda structure");
 	// ---- per-vertex contribution lists in edge order: (edge, side)

@@ -6,6 +6,8 @@
 #include <stdint.h>
 #include <string>
 #include <vector>
+#include <exception>
+#include <thread>
 #include <stdexcept>
 #include <algorithm>
 #include <string.h>
@@ -389,5 +391,55 @@ void phases_collect(spp_ctx *ctx);
 // dominant-kernel event bracket
 void dom_begin(spp_ctx *ctx);
 void dom_end(spp_ctx *ctx, double flops);
+
+// ---- host threads of the symbolic phases (spp_symbolic.cpp, spp_assemble.hip)
+// Runs fn(t) for t = 0 .. nt-1 on nt host threads (fn(0) on the caller's). The symbolic phase is integer work over
+// tens of millions of block products; its passes are cut into independent pieces with precomputed output offsets, so
+// the result does not depend on the number of threads.
+template <class F>
+inline void run_threads(int nt, F fn)
+{
+	if(nt <= 1) {
+		fn(0);
+		return;
+	}
+	std::vector<std::thread> th;
+	std::exception_ptr err[64];
+	for(int t = 1; t < nt; ++ t)
+		th.emplace_back([&, t]() { try { fn(t); } catch(...) { err[t] = std::current_exception(); } });
+	try { fn(0); } catch(...) { err[0] = std::current_exception(); }
+	for(size_t t = 0; t < th.size(); ++ t)
+		th[t].join();
+	for(int t = 0; t < nt; ++ t)
+		if(err[t])
+			std::rethrow_exception(err[t]);
+}
+
+inline int plan_threads(int64_t work)
+{
+	static int env = -1;
+	if(env < 0) {
+		const char *e = getenv("SPP_PLAN_THREADS"); // host threads of the symbolic phase (default: up to 16)
+		env = e ? std::max(1, atoi(e)) : 0;
+	}
+	int nt = env ? env : (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+	if(work < (int64_t(1) << 18))
+		nt = 1; // small problems: a thread costs more than it saves
+	return std::min(nt, 64);
+}
+
+// cut [0, n) into nt pieces of about equal weight; w_prefix has n + 1 entries (w_prefix[0] = 0)
+inline void balanced_cuts(const std::vector<int64_t> &w_prefix, int nt, std::vector<int64_t> &cut)
+{
+	const int64_t n = (int64_t)w_prefix.size() - 1, total = w_prefix[n];
+	cut.assign(nt + 1, n);
+	cut[0] = 0;
+	for(int t = 1; t < nt; ++ t)
+		cut[t] = std::lower_bound(w_prefix.begin(), w_prefix.end(), total * t / nt) - w_prefix.begin();
+	for(int t = 1; t <= nt; ++ t)
+		cut[t] = std::max(cut[t], cut[t - 1]);
+	cut[nt] = n;
+}
+
 
 } // namespace spp
