@@ -76,10 +76,13 @@ void assemble_analyze(spp_ctx *ctx, int64_t nv, const int32_t *dim, int64_t ne, 
 	SPP_REQUIRE(ne < (int64_t(1) << 30), SPP_E_UNSUPPORTED, "too many edges for 31-bit edge indices");
 	assemble_release(ctx); // after a rejected call the ctx has NO assembly plan (spp_assemble_device then fails its state check)
 	VClock clk("assemble_analyze");
-	for(int64_t e = 0; e < ne; ++ e) {
-		SPP_REQUIRE(v0[e] >= 0 && v0[e] < nv && v1[e] >= 0 && v1[e] < nv && v0[e] != v1[e], SPP_E_BADARG, "bad edge");
-		SPP_REQUIRE(dim[v0[e]] == d0 && dim[v1[e]] == d1, SPP_E_BADARG, "vertex width does not match the edge group");
-	}
+	const int nt = plan_threads(ne);
+	run_threads(nt, [&](int t) {
+		for(int64_t e = ne * t / nt, e1 = ne * (t + 1) / nt; e < e1; ++ e) {
+			SPP_REQUIRE(v0[e] >= 0 && v0[e] < nv && v1[e] >= 0 && v1[e] < nv && v0[e] != v1[e], SPP_E_BADARG, "bad edge");
+			SPP_REQUIRE(dim[v0[e]] == d0 && dim[v1[e]] == d1, SPP_E_BADARG, "vertex width does not match the edge group");
+		}
+	});
 	SPP_REQUIRE(unary_vertex < nv, SPP_E_BADARG, "unary_vertex out of range");
 	// built in a local object, installed in the ctx only when complete
 	struct PlanGuard { AssemblePlan *p; ~PlanGuard() { delete p; } } guard = {new AssemblePlan};
@@ -87,15 +90,16 @@ void assemble_analyze(spp_ctx *ctx, int64_t nv, const int32_t *dim, int64_t ne, 
 	ap->d0 = d0; ap->d1 = d1; ap->rd = rd; ap->nv = nv; ap->ne = ne; ap->unary_vertex = unary_vertex;
 	// ---- Lambda structure: diagonal of every vertex + upper block of every edge
 	// (_Lambda_Base.h:1863-1881 builds all block rows/cols first, then :1897 allocates edge blocks)
-	std::vector<std::pair<int64_t, int64_t> > key(ne); // (col, row)
-	for(int64_t e = 0; e < ne; ++ e)
-		key[e] = std::make_pair(std::max(v0[e], v1[e]), std::min(v0[e], v1[e]));
+	HVec<std::pair<int64_t, int64_t> > key(ne); // (col, row)
+	run_threads(nt, [&](int t) {
+		for(int64_t e = ne * t / nt, e1 = ne * (t + 1) / nt; e < e1; ++ e)
+			key[e] = std::make_pair(std::max(v0[e], v1[e]), std::min(v0[e], v1[e]));
+	});
 	// edges in (column, row, edge index) order: a counting sort by column (stable), then the rows inside each column --
 	// a handful per landmark column -- by insertion, longer runs by std::stable_sort (a comparison sort of all the
 	// edges was most of this function on a Venice-sized graph)
-	std::vector<int64_t> eorder(ne);
+	HVec<int64_t> eorder(ne);
 	std::vector<int64_t> cstart(nv + 1, 0); // edges of column c: eorder[cstart[c] .. cstart[c + 1])
-	const int nt = plan_threads(ne);
 	std::vector<int64_t> ccut; // ranges of columns with about equal numbers of edges (+ 1 per column)
 	{
 		for(int64_t e = 0; e < ne; ++ e)
@@ -142,7 +146,7 @@ void assemble_analyze(spp_ctx *ctx, int64_t nv, const int32_t *dim, int64_t ne, 
 	// Columns are independent once the edges are in block order: a first pass counts the blocks and values of every column
 	// (ranges of columns on host threads), a serial prefix gives every column its place, a second pass writes.
 	st.col_ptr.assign(nv + 1, 0);
-	std::vector<int64_t> v_doff(nv), c_ob(nv + 1, 0), c_off(nv + 1, 0); // per column: first off-diagonal block, first value
+	HVec<int64_t> v_doff(nv), c_ob(nv + 1, 0), c_off(nv + 1, 0); // per column: first off-diagonal block, first value
 	run_threads(nt, [&](int t) {
 		for(int64_t c = ccut[t]; c < ccut[t + 1]; ++ c) {
 			int64_t nblk = 0, nval = 0, rprev = -1;
@@ -166,8 +170,8 @@ void assemble_analyze(spp_ctx *ctx, int64_t nv, const int32_t *dim, int64_t ne, 
 	st.nnzb = st.col_ptr[nv];
 	st.nvals = c_off[nv];
 	const int64_t n_ob = c_ob[nv];
-	std::vector<int32_t> ob_ptr(n_ob + 1), ob_edge(ne);
-	std::vector<int64_t> ob_off(n_ob);
+	HVec<int32_t> ob_ptr(n_ob + 1), ob_edge(ne);
+	HVec<int64_t> ob_off(n_ob);
 	ob_ptr[0] = 0;
 	st.row_idx.resize(st.nnzb);
 	st.blk_off.resize(st.nnzb);
@@ -196,7 +200,7 @@ void assemble_analyze(spp_ctx *ctx, int64_t nv, const int32_t *dim, int64_t ne, 
 	ap->n_ob = (int64_t)ob_off.size();
 	clk.lap("Lambda structure");
 	// ---- per-vertex contribution lists in edge order: (edge, side)
-	std::vector<int32_t> vl_ptr(nv + 1, 0), vl_entry(2 * ne);
+	HVec<int32_t> vl_ptr(nv + 1, 0), vl_entry(2 * ne);
 	for(int64_t e = 0; e < ne; ++ e) {
 		++ vl_ptr[v0[e] + 1];
 		++ vl_ptr[v1[e] + 1];

@@ -6,6 +6,9 @@
 #include <stdint.h>
 #include <string>
 #include <vector>
+#include <sys/mman.h>
+#include <utility>
+#include <new>
 #include <exception>
 #include <thread>
 #include <stdexcept>
@@ -63,6 +66,41 @@ struct VClock {
 // device buffer (owned, grows geometrically like the reference's workspaces,
 // LinearSolver_UberBlock.h:332-348)
 // ------------------------------------------------------------------------------------------------
+// Host arrays of the symbolic phases: tens of MB each, written once front to back. Two costs of a plain std::vector
+// dominate them -- the value-initialization of resize() (a serial memset) and the first touch in 4 KB pages (63 000
+// page faults per 260 MB) -- so big blocks come 2 MB-aligned and offered to transparent huge pages, and elements of
+// trivial type are default-initialized (NOT zeroed: every user writes before it reads).
+template <class T>
+struct HugeAlloc {
+	typedef T value_type;
+	HugeAlloc() {}
+	template <class U> HugeAlloc(const HugeAlloc<U>&) {}
+	T *allocate(size_t n)
+	{
+		const size_t bytes = n * sizeof(T), huge = (size_t)2 << 20;
+		void *q = nullptr;
+		if(bytes >= ((size_t)4 << 20)) {
+			if(posix_memalign(&q, huge, (bytes + huge - 1) & ~(huge - 1)) != 0)
+				q = nullptr;
+#ifdef MADV_HUGEPAGE
+			if(q)
+				madvise(q, bytes, MADV_HUGEPAGE);
+#endif
+		}
+		if(!q)
+			q = malloc(bytes ? bytes : 1);
+		if(!q)
+			throw std::bad_alloc();
+		return (T*)q;
+	}
+	void deallocate(T *p, size_t) { free(p); }
+	template <class U> void construct(U *p) { ::new((void*)p) U; } // default-init
+	template <class U, class A0, class... A> void construct(U *p, A0 &&a0, A &&... a) { ::new((void*)p) U(std::forward<A0>(a0), std::forward<A>(a)...); }
+	template <class U> bool operator==(const HugeAlloc<U>&) const { return true; }
+	template <class U> bool operator!=(const HugeAlloc<U>&) const { return false; }
+};
+template <class T> using HVec = std::vector<T, HugeAlloc<T> >;
+
 template <class T>
 struct DevBuf {
 	T *p = nullptr;
@@ -100,7 +138,8 @@ struct DevBuf {
 		}
 		cap = want;
 	}
-	void upload(const std::vector<T> &h, hipStream_t s)
+	template <class A>
+	void upload(const std::vector<T, A> &h, hipStream_t s)
 	{
 		reserve(h.size() ? h.size() : 1);
 		if(!h.empty())
@@ -118,8 +157,8 @@ struct UploadArena {
 	struct Item { void **pp; size_t *pcap; bool *powned; size_t off, n; };
 	std::vector<Item> items;
 	explicit UploadArena(hipStream_t s) : stream(s) { host.reserve(size_t(1) << 20); }
-	template <class T>
-	void add(DevBuf<T> &b, const std::vector<T> &v)
+	template <class T, class A>
+	void add(DevBuf<T> &b, const std::vector<T, A> &v)
 	{
 		if(v.size() * sizeof(T) > (size_t(256) << 10)) { // a large array gains nothing from being staged twice: its own upload
 			b.upload(v, stream);
@@ -152,8 +191,8 @@ struct UploadArena {
 // ------------------------------------------------------------------------------------------------
 struct Structure {
 	int64_t nb = 0, n = 0, nnzb = 0, nvals = 0;
-	std::vector<int64_t> col_ptr, row_idx, blk_off, base;
-	std::vector<int32_t> dim;
+	HVec<int64_t> col_ptr, row_idx, blk_off, base;
+	HVec<int32_t> dim;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -429,7 +468,8 @@ inline int plan_threads(int64_t work)
 }
 
 // cut [0, n) into nt pieces of about equal weight; w_prefix has n + 1 entries (w_prefix[0] = 0)
-inline void balanced_cuts(const std::vector<int64_t> &w_prefix, int nt, std::vector<int64_t> &cut)
+template <class V>
+inline void balanced_cuts(const V &w_prefix, int nt, std::vector<int64_t> &cut)
 {
 	const int64_t n = (int64_t)w_prefix.size() - 1, total = w_prefix[n];
 	cut.assign(nt + 1, n);

@@ -341,7 +341,6 @@ void sparse_analyze(spp_ctx *ctx, const Structure &st)
 	// relaxed amalgamation: merge supernode s into the supernode that starts right after it when
 	// that one is its parent and the explicit zeros stay small
 	{
-		std::vector<int64_t> base = st.base; // unused here, dims through order
 		std::vector<int32_t> pdim(nb);
 		for(int64_t k = 0; k < nb; ++ k)
 			pdim[k] = st.dim[order[k]];

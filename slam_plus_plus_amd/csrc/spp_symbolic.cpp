@@ -168,9 +168,11 @@ struct SchurPlanHost {
 	bool u_landmark_major = true, factored = true;
 	std::vector<int64_t> pose_block, lm_block;
 	std::vector<uint8_t> is_lm;
-	std::vector<int32_t> lm_ptr, obs_pose, obs_lm, cam_ptr, cam_obs, wpos, sblk_i1, sblk_i2, multi_blk, multi_ptr, xb;
+	HVec<int32_t> lm_ptr, obs_pose, obs_lm, cam_obs, wpos; // (per observation / landmark: HVec = not zero-filled, huge pages)
+	std::vector<int32_t> cam_ptr, sblk_i1, sblk_i2, multi_blk, multi_ptr, xb;
 	RawBuf<int32_t> pair_a, pair_b; // (tens of millions of entries: not value-initialized, first touched by the threads that fill them)
-	std::vector<int64_t> lm_coff, obs_off, sblk_aoff, sblk_voff, pose_rbase, lm_rbase;
+	HVec<int64_t> lm_coff, obs_off, lm_rbase;
+	std::vector<int64_t> sblk_aoff, sblk_voff, pose_rbase;
 	std::vector<SaccItem> recs;
 	Structure s_st;
 };
@@ -222,12 +224,12 @@ static void schur_plan_host(const Structure &st, int shard_rank, int shard_world
 	// ---- observations: every pose-landmark block, sorted by (landmark, pose). Two passes over ranges of columns on host
 	// threads: counts per range, then every range writes its observations / camera-camera blocks at its offset.
 	struct Obs { int32_t lm, pose; int64_t off; };
-	std::vector<int64_t> &lm_coff = h.lm_coff;
+	HVec<int64_t> &lm_coff = h.lm_coff;
 	lm_coff.assign(nl, -1);
 	struct ABlk { int32_t i1, i2; int64_t off; };
 	std::vector<ABlk> ablk;
-	std::vector<int32_t> &lm_ptr = h.lm_ptr, &obs_pose = h.obs_pose, &obs_lm = h.obs_lm;
-	std::vector<int64_t> &obs_off = h.obs_off;
+	HVec<int32_t> &lm_ptr = h.lm_ptr, &obs_pose = h.obs_pose, &obs_lm = h.obs_lm;
+	HVec<int64_t> &obs_off = h.obs_off;
 	bool obs_sorted = true;
 	const int nts = plan_threads(st.nnzb);
 	std::vector<int64_t> jcut;
@@ -376,12 +378,13 @@ static void schur_plan_host(const Structure &st, int shard_rank, int shard_world
 
 	// ---- per-pose observation lists (ascending landmark = ascending obs index): a counting sort by camera, ranges of
 	// observations on host threads (per-range, per-camera counts give every range its place in every camera's list)
-	std::vector<int32_t> &cam_ptr = h.cam_ptr, &cam_obs = h.cam_obs;
+	std::vector<int32_t> &cam_ptr = h.cam_ptr;
+	HVec<int32_t> &cam_obs = h.cam_obs;
 	cam_ptr.assign(nc + 1, 0);
 	cam_obs.resize(no);
 	// (beside every entry: where the observations of its landmark end -- the pair lists below walk [a, cam_end) per entry and
 	// would otherwise chase cam_obs -> obs_lm -> lm_ptr, three dependent cache misses, per observation)
-	std::vector<int32_t> cam_end(no);
+	HVec<int32_t> cam_end(no);
 	{
 		std::vector<int32_t> cnt((size_t)nto * nc, 0); // [range][camera]
 		run_threads(nto, [&](int t) {
@@ -410,7 +413,7 @@ static void schur_plan_host(const Structure &st, int shard_rank, int shard_world
 
 	// camera-major position of every observation: W, Up, xw are stored in this order, so that the
 	// blocks one camera contributes are contiguous (the S accumulation gathers them per camera pair)
-	std::vector<int32_t> &wpos = h.wpos;
+	HVec<int32_t> &wpos = h.wpos;
 	wpos.resize(no);
 	run_threads(nto, [&](int t) {
 		for(int64_t q = no * t / nto, q1 = no * (t + 1) / nto; q < q1; ++ q)
