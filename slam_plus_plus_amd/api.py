@@ -352,7 +352,7 @@ class Context:
         blk_off = np.empty(nnzb, dtype=np.int64)
         self._check(self.lib.spp_assemble_get_structure(self.h, _ptr(col_ptr), _ptr(row_idx), _ptr(blk_off)))
         from .blockcsc import BlockCSC
-        return BlockCSC(dim, col_ptr, row_idx, blk_off, None)
+        return BlockCSC(dim, col_ptr, row_idx, blk_off, None, nvals=self.info("NVALS"))
 
     def assemble_set_edge_weights(self, d_w):
         """robust edges: device array of one weight per edge for the following assemble_device calls (None: plain edges)"""

@@ -7,7 +7,10 @@ import numpy as np
 
 
 class BlockCSC:
-    def __init__(self, dim, col_ptr, row_idx, blk_off, vals):
+    def __init__(self, dim, col_ptr, row_idx, blk_off, vals, nvals=None):
+        """nvals: the length of the value array when the caller knows it (the library reports it); col_idx (the column of
+        every block) and nvals are otherwise derived on first use -- on a Venice-sized structure (3.4 M blocks) those
+        passes cost more than the library's whole assembly plan"""
         self.dim = np.ascontiguousarray(dim, dtype=np.int32)
         self.col_ptr = np.ascontiguousarray(col_ptr, dtype=np.int64)
         self.row_idx = np.ascontiguousarray(row_idx, dtype=np.int64)
@@ -18,12 +21,23 @@ class BlockCSC:
         self.base = np.zeros(self.nb + 1, dtype=np.int64)
         np.cumsum(self.dim, out=self.base[1:])
         self.n = int(self.base[-1])
-        cols = np.repeat(np.arange(self.nb, dtype=np.int64), np.diff(self.col_ptr))
-        self.col_idx = cols
-        self.nvals = int((self.blk_off + self.dim[self.row_idx].astype(np.int64) * self.dim[cols]).max()) if self.nnzb else 0
+        self._col_idx = None
+        self._nvals = None if nvals is None else int(nvals)
+
+    @property
+    def col_idx(self):
+        if self._col_idx is None:
+            self._col_idx = np.repeat(np.arange(self.nb, dtype=np.int64), np.diff(self.col_ptr))
+        return self._col_idx
+
+    @property
+    def nvals(self):
+        if self._nvals is None:
+            self._nvals = int((self.blk_off + self.dim[self.row_idx].astype(np.int64) * self.dim[self.col_idx]).max()) if self.nnzb else 0
+        return self._nvals
 
     def with_vals(self, vals):
-        return BlockCSC(self.dim, self.col_ptr, self.row_idx, self.blk_off, vals)
+        return BlockCSC(self.dim, self.col_ptr, self.row_idx, self.blk_off, vals, self._nvals)
 
     def to_dense(self, symmetric=True):
         """Dense n x n matrix (mirrors the upper triangle when symmetric=True). Small cases only."""

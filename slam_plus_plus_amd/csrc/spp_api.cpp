@@ -269,8 +269,9 @@ int spp_analyze(spp_ctx *ctx, int64_t nb, const int64_t *col_ptr, const int64_t 
 	st.nb = nb;
 	st.nnzb = col_ptr[nb];
 	st.col_ptr.assign(col_ptr, col_ptr + nb + 1);
-	st.row_idx.assign(row_idx, row_idx + st.nnzb);
-	st.blk_off.assign(blk_off, blk_off + st.nnzb);
+	SPP_REQUIRE(st.nnzb >= nb, SPP_E_BADARG, "spp_analyze: fewer blocks than block columns");
+	for(int64_t j = 0; j < nb; ++ j)
+		SPP_REQUIRE(col_ptr[j + 1] > col_ptr[j], SPP_E_BADARG, "every block column needs its diagonal block");
 	st.dim.assign(dim, dim + nb);
 	st.base.resize(nb + 1);
 	st.base[0] = 0;
@@ -281,17 +282,35 @@ int spp_analyze(spp_ctx *ctx, int64_t nb, const int64_t *col_ptr, const int64_t 
 		st.base[j + 1] = st.base[j] + dim[j];
 	}
 	st.n = st.base[nb];
-	st.nvals = 0;
-	for(int64_t j = 0; j < nb; ++ j) {
-		SPP_REQUIRE(col_ptr[j + 1] > col_ptr[j], SPP_E_BADARG, "every block column needs its diagonal block");
-		for(int64_t p = col_ptr[j]; p < col_ptr[j + 1]; ++ p) {
-			const int64_t i = row_idx[p];
-			SPP_REQUIRE(i >= 0 && i <= j, SPP_E_BADARG, "only the upper triangle may be stored");
-			SPP_REQUIRE(p == col_ptr[j] || row_idx[p - 1] < i, SPP_E_BADARG, "rows must ascend within a column");
-			SPP_REQUIRE(blk_off[p] >= 0, SPP_E_BADARG, "negative block offset");
-			st.nvals = std::max<int64_t>(st.nvals, blk_off[p] + (int64_t)dim[i] * dim[j]);
-		}
-		SPP_REQUIRE(row_idx[col_ptr[j + 1] - 1] == j, SPP_E_BADARG, "diagonal block missing (must be last in its column)");
+	// the block lists are copied and checked by ranges of columns on host threads (54 MB on a Venice-sized structure)
+	st.row_idx.resize(st.nnzb);
+	st.blk_off.resize(st.nnzb);
+	{
+		const int nt = plan_threads(st.nnzb);
+		std::vector<int64_t> jcut, nvals_t(nt, 0);
+		balanced_cuts(st.col_ptr, nt, jcut);
+		run_threads(nt, [&](int t) {
+			const int64_t p0 = col_ptr[jcut[t]], p1 = col_ptr[jcut[t + 1]];
+			if(p1 > p0) {
+				memcpy(st.row_idx.data() + p0, row_idx + p0, (size_t)(p1 - p0) * sizeof(int64_t));
+				memcpy(st.blk_off.data() + p0, blk_off + p0, (size_t)(p1 - p0) * sizeof(int64_t));
+			}
+			int64_t nv = 0;
+			for(int64_t j = jcut[t]; j < jcut[t + 1]; ++ j) {
+				for(int64_t p = col_ptr[j]; p < col_ptr[j + 1]; ++ p) {
+					const int64_t i = row_idx[p];
+					SPP_REQUIRE(i >= 0 && i <= j, SPP_E_BADARG, "only the upper triangle may be stored");
+					SPP_REQUIRE(p == col_ptr[j] || row_idx[p - 1] < i, SPP_E_BADARG, "rows must ascend within a column");
+					SPP_REQUIRE(blk_off[p] >= 0, SPP_E_BADARG, "negative block offset");
+					nv = std::max<int64_t>(nv, blk_off[p] + (int64_t)dim[i] * dim[j]);
+				}
+				SPP_REQUIRE(row_idx[col_ptr[j + 1] - 1] == j, SPP_E_BADARG, "diagonal block missing (must be last in its column)");
+			}
+			nvals_t[t] = nv;
+		});
+		st.nvals = 0;
+		for(int t = 0; t < nt; ++ t)
+			st.nvals = std::max(st.nvals, nvals_t[t]);
 	}
 	ctx->st = std::move(st);
 	Structure &st_ref = ctx->st;
@@ -323,6 +342,7 @@ int spp_analyze(spp_ctx *ctx, int64_t nb, const int64_t *col_ptr, const int64_t 
 		build_schur_plan(ctx, sparse_S, mis);
 		ctx->schur.mis = mis;
 		ctx->order.clear();
+		ctx->order.reserve((size_t)st_ref.nb);
 		if(sparse_S) {
 			sparse_analyze(ctx, ctx->schur.s_st); // leaves the elimination order of the reduced poses in ctx->order
 			std::vector<int64_t> red = ctx->order;

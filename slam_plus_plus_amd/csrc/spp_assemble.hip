@@ -95,20 +95,26 @@ void assemble_analyze(spp_ctx *ctx, int64_t nv, const int32_t *dim, int64_t ne, 
 		for(int64_t e = ne * t / nt, e1 = ne * (t + 1) / nt; e < e1; ++ e)
 			key[e] = std::make_pair(std::max(v0[e], v1[e]), std::min(v0[e], v1[e]));
 	});
-	// edges in (column, row, edge index) order: a counting sort by column (stable), then the rows inside each column --
-	// a handful per landmark column -- by insertion, longer runs by std::stable_sort (a comparison sort of all the
-	// edges was most of this function on a Venice-sized graph)
+	// edges in (column, row, edge index) order: a counting sort by column, then (row, edge) inside each column -- a handful
+	// per landmark column -- by insertion, longer runs by std::sort (a comparison sort of all the edges was most of this
+	// function on a Venice-sized graph)
 	HVec<int64_t> eorder(ne);
 	std::vector<int64_t> cstart(nv + 1, 0); // edges of column c: eorder[cstart[c] .. cstart[c + 1])
 	std::vector<int64_t> ccut; // ranges of columns with about equal numbers of edges (+ 1 per column)
 	{
-		for(int64_t e = 0; e < ne; ++ e)
-			++ cstart[key[e].first + 1];
+		// counted and scattered by all threads with atomic increments; the scatter is then in no particular order, the sort
+		// inside each column is by (row, edge index) and restores it
+		run_threads(nt, [&](int t) {
+			for(int64_t e = ne * t / nt, e1 = ne * (t + 1) / nt; e < e1; ++ e)
+				__atomic_fetch_add(&cstart[key[e].first + 1], (int64_t)1, __ATOMIC_RELAXED);
+		});
 		for(int64_t c = 0; c < nv; ++ c)
 			cstart[c + 1] += cstart[c];
 		std::vector<int64_t> fill(cstart.begin(), cstart.end() - 1);
-		for(int64_t e = 0; e < ne; ++ e)
-			eorder[fill[key[e].first] ++] = e;
+		run_threads(nt, [&](int t) {
+			for(int64_t e = ne * t / nt, e1 = ne * (t + 1) / nt; e < e1; ++ e)
+				eorder[__atomic_fetch_add(&fill[key[e].first], (int64_t)1, __ATOMIC_RELAXED)] = e;
+		});
 		{
 			std::vector<int64_t> w(nv + 1);
 			for(int64_t c = 0; c <= nv; ++ c)
@@ -121,14 +127,19 @@ void assemble_analyze(spp_ctx *ctx, int64_t nv, const int32_t *dim, int64_t ne, 
 			if(n <= 1)
 				continue;
 			if(n > 32) {
-				std::stable_sort(eorder.begin() + b, eorder.begin() + b + n, [&](int64_t x, int64_t y) { return key[x].second < key[y].second; });
+				std::sort(eorder.begin() + b, eorder.begin() + b + n, [&](int64_t x, int64_t y) {
+					return key[x].second != key[y].second ? key[x].second < key[y].second : x < y; });
 				continue;
 			}
-			for(int64_t i = 1; i < n; ++ i) { // stable insertion sort by row
+			for(int64_t i = 1; i < n; ++ i) { // insertion sort by (row, edge)
 				const int64_t x = eorder[b + i], rx = key[x].second;
 				int64_t j = i;
-				for(; j > 0 && key[eorder[b + j - 1]].second > rx; -- j)
-					eorder[b + j] = eorder[b + j - 1];
+				for(; j > 0; -- j) {
+					const int64_t y = eorder[b + j - 1], ry = key[y].second;
+					if(ry < rx || (ry == rx && y < x))
+						break;
+					eorder[b + j] = y;
+				}
 				eorder[b + j] = x;
 			}
 		}

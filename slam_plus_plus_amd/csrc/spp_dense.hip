@@ -1172,9 +1172,9 @@ static void ensure_dense_work(spp_ctx *ctx, int64_t nblk)
 		const char *r = getenv("SPP_AUX_RESERVE_CUS");
 		const int reserve = r ? atoi(r) : 32;
 		if(reserve > 0) {
-			hipDeviceProp_t prop;
-			SPP_HIP_CHECK(hipGetDeviceProperties(&prop, ctx->device));
-			const int ncu = prop.multiProcessorCount, nw = (ncu + 31) / 32;
+			int ncu = 0; // (one attribute: hipGetDeviceProperties fills a 1.5 KB record through dozens of driver queries, milliseconds)
+			SPP_HIP_CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
+			const int nw = (ncu + 31) / 32;
 			std::vector<uint32_t> mask((size_t)nw, 0u);
 			for(int c = reserve; c < ncu; ++ c)
 				mask[(size_t)c / 32] |= 1u << (c % 32);
