@@ -152,10 +152,12 @@ void spp_destroy(spp_ctx *ctx)
 {
 	if(!ctx)
 		return;
+	if(ctx->plan_trash.joinable())
+		ctx->plan_trash.join();
 	spp_free_memory(ctx);
 	ctx->dense.info.release();
 	if(ctx->dense.aux) {
-		(void)hipStreamDestroy(ctx->dense.aux);
+		dense_aux_park(ctx->device, ctx->dense.aux); // (kept for the next context of this device: creating it is ~10 ms)
 		(void)hipEventDestroy(ctx->dense.ev[0]);
 		(void)hipEventDestroy(ctx->dense.ev[1]);
 	}
@@ -340,6 +342,7 @@ int spp_analyze(spp_ctx *ctx, int64_t nb, const int64_t *col_ptr, const int64_t 
 		const bool mis = chosen == SPP_MODE_SCHUR_MIS;
 		const bool sparse_S = chosen != SPP_MODE_SCHUR; // the reduced system of a pose graph is sparse
 		build_schur_plan(ctx, sparse_S, mis);
+		clk.lap("schur plan (all of it)");
 		ctx->schur.mis = mis;
 		ctx->order.clear();
 		ctx->order.reserve((size_t)st_ref.nb);
@@ -361,6 +364,7 @@ int spp_analyze(spp_ctx *ctx, int64_t nb, const int64_t *col_ptr, const int64_t 
 	} else
 		sparse_analyze(ctx, ctx->st);
 	ctx->mode = chosen;
+	clk.lap("plan + ordering");
 	return SPP_OK;
 	SPP_CATCH(ctx)
 }

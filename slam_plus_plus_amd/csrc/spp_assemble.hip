@@ -212,6 +212,8 @@ void assemble_analyze(spp_ctx *ctx, int64_t nv, const int32_t *dim, int64_t ne, 
 	clk.lap("Lambda structure");
 	// ---- per-vertex contribution lists in edge order: (edge, side)
 	HVec<int32_t> vl_ptr(nv + 1, 0), vl_entry(2 * ne);
+	// (serial: the camera side of a BA graph is a few hundred counters that every edge increments -- atomic increments from
+	// 16 threads on them measured 125 ms against 7 ms for this loop)
 	for(int64_t e = 0; e < ne; ++ e) {
 		++ vl_ptr[v0[e] + 1];
 		++ vl_ptr[v1[e] + 1];
@@ -219,7 +221,7 @@ void assemble_analyze(spp_ctx *ctx, int64_t nv, const int32_t *dim, int64_t ne, 
 	for(int64_t v = 0; v < nv; ++ v)
 		vl_ptr[v + 1] += vl_ptr[v];
 	{
-		std::vector<int32_t> fill(vl_ptr.begin(), vl_ptr.end() - 1);
+		HVec<int32_t> fill(vl_ptr.begin(), vl_ptr.end() - 1);
 		for(int64_t e = 0; e < ne; ++ e) { // within an edge vertex 0 registers before vertex 1
 			vl_entry[fill[v0[e]] ++] = (int32_t)(e << 1);
 			vl_entry[fill[v1[e]] ++] = (int32_t)(e << 1) | 1;

@@ -35,6 +35,7 @@
 #include <string.h>
 #include <algorithm>
 #include <vector>
+#include <mutex>
 
 namespace spp {
 
@@ -1155,15 +1156,55 @@ static void ensure_info(spp_ctx *ctx)
 	}
 }
 
+// A stream with a CU mask takes ~10 ms to create (measured: a fifth of the whole analysis of a Venice-sized problem): a
+// closed context parks its bulk stream here and the next context on the same device takes it over. (The mask depends on
+// SPP_AUX_RESERVE_CUS alone, which is read once per process.)
+static std::mutex aux_pool_mutex;
+static std::vector<std::pair<int, hipStream_t> > aux_pool;
+
+static hipStream_t dense_aux_take(int device)
+{
+	std::lock_guard<std::mutex> lock(aux_pool_mutex);
+	for(size_t i = 0; i < aux_pool.size(); ++ i)
+		if(aux_pool[i].first == device) {
+			hipStream_t s = aux_pool[i].second;
+			aux_pool.erase(aux_pool.begin() + i);
+			return s;
+		}
+	return nullptr;
+}
+
+void dense_aux_park(int device, hipStream_t s)
+{
+	if(hipStreamSynchronize(s) != hipSuccess) {
+		(void)hipGetLastError();
+		(void)hipStreamDestroy(s);
+		return;
+	}
+	std::lock_guard<std::mutex> lock(aux_pool_mutex);
+	if(aux_pool.size() >= 16) {
+		(void)hipStreamDestroy(s);
+		return;
+	}
+	aux_pool.push_back(std::make_pair(device, s));
+}
+
 static void ensure_dense_work(spp_ctx *ctx, int64_t nblk)
 {
+	VClock clk("dense workspaces");
 	ensure_info(ctx);
+	clk.lap("status words");
 	if(ctx->dense.tinv_all.cap < (size_t)nblk * NB * NB) {
 		// zeroed once: the lookahead schedule never stores the zeros below the diagonal of a block's inverse
 		ctx->dense.tinv_all.reserve((size_t)nblk * NB * NB);
 		SPP_HIP_CHECK(hipMemsetAsync(ctx->dense.tinv_all.p, 0, ctx->dense.tinv_all.cap * sizeof(double), ctx->stream));
 	}
 	ctx->dense.xtmp.reserve((size_t)(nblk + 1) * NB);
+	clk.lap("block inverses");
+	if(!ctx->dense.aux && (ctx->dense.aux = dense_aux_take(ctx->device)) != nullptr) {
+		SPP_HIP_CHECK(hipEventCreateWithFlags(&ctx->dense.ev[0], hipEventDisableTiming));
+		SPP_HIP_CHECK(hipEventCreateWithFlags(&ctx->dense.ev[1], hipEventDisableTiming));
+	}
 	if(!ctx->dense.aux) {
 		// The bulk stream is created with a CU mask that leaves the first n CUs (SPP_AUX_RESERVE_CUS, default 32)
 		// to the chain: under a running bulk update every wave slot of the chip is taken, potrf_diag and the
@@ -1193,6 +1234,7 @@ static void ensure_dense_work(spp_ctx *ctx, int64_t nblk)
 		SPP_HIP_CHECK(hipEventCreateWithFlags(&ctx->dense.ev[0], hipEventDisableTiming));
 		SPP_HIP_CHECK(hipEventCreateWithFlags(&ctx->dense.ev[1], hipEventDisableTiming));
 	}
+	clk.lap("bulk stream + events");
 	static uint64_t attr_set_seen = 0;
 	if(first_on_this_device(attr_set_seen)) {
 		SPP_HIP_CHECK(hipFuncSetAttribute((const void*)potrf_diag_kernel,

@@ -335,6 +335,7 @@ struct spp_ctx {
 	int shard_rank = 0, shard_world = 1;
 	spp::Structure st;
 	std::vector<int64_t> order; // elimination order (block columns)
+	std::thread plan_trash; // releases the host image of the last Schur plan (hundreds of MB) beside the caller; joined by the next analysis and by spp_destroy
 	spp::SchurPlan schur;
 	spp::DenseWork dense;
 	spp::SparsePlan *sparse = nullptr;
@@ -399,6 +400,7 @@ int dense_potrf_upper(spp_ctx *ctx, double *d_A, int64_t n, int64_t ld, bool kee
 void dense_potrf_upper_enqueue(spp_ctx *ctx, double *d_A, int64_t n, int64_t ld);
 int dense_info_fetch(spp_ctx *ctx, bool *dag_aborted = nullptr); // dag_aborted given: a timed-out sparse launch is reported there instead of thrown
 void dense_potrs_upper(spp_ctx *ctx, const double *d_R, int64_t n, int64_t ld, double *d_b);
+void dense_aux_park(int device, hipStream_t s); // hands the bulk stream of a closing context to the next one
 void dense_factor_steps(spp_ctx *ctx, double *d_A, int64_t ld, int64_t n, int64_t rows, int64_t ncols,
 	int64_t nsteps, bool has_rhs);
 void dense_info_reset(spp_ctx *ctx);

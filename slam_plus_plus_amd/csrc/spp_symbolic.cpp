@@ -21,6 +21,7 @@
 #include <stdlib.h>
 #include <stdio.h>
 #include <thread>
+#include <memory>
 #include <chrono>
 #include <exception>
 
@@ -764,6 +765,7 @@ static void schur_plan_host(const Structure &st, int shard_rank, int shard_world
 			}
 		}
 	}
+	clk.lap("item records");
 }
 
 void build_schur_plan(spp_ctx *ctx, bool sparse_S, bool mis)
@@ -773,7 +775,10 @@ void build_schur_plan(spp_ctx *ctx, bool sparse_S, bool mis)
 	sp.release_all();
 	sp.sparse_S = sparse_S;
 	hipStream_t s = ctx->stream;
-	SchurPlanHost h;
+	VClock clk0("schur plan (device)");
+	std::unique_ptr<SchurPlanHost> hp(new SchurPlanHost);
+	SchurPlanHost &h = *hp;
+	clk0.lap("old plan released");
 	schur_plan_host(st, ctx->shard_rank, ctx->shard_world, sparse_S, mis, h);
 	VClock clk("schur plan (device)");
 	const int dp = h.dp, dl = h.dl;
@@ -851,6 +856,19 @@ void build_schur_plan(spp_ctx *ctx, bool sparse_S, bool mis)
 	ctx->solve_bytes = blk_pl * no + blk_ll * nl + blk_pp * h.n_ablk + 8 * st.n /* read */
 		+ blk_pp * sp.n_sblk + 8 * st.n /* write S, solution */
 		+ 8 * sp.n_red * sp.n_red /* dense factor touched once in place */;
+	// the host image (pair lists, observation lists: ~250 MB on a Venice-sized problem, 8 ms to unmap) is released beside
+	// the caller
+	if(ctx->plan_trash.joinable())
+		ctx->plan_trash.join();
+	{
+		SchurPlanHost *raw = hp.release();
+		try {
+			ctx->plan_trash = std::thread([raw]() { delete raw; });
+		} catch(...) {
+			delete raw;
+		}
+	}
+	clk.lap("host plan handed to the releasing thread");
 }
 
 // host-only: the symbolic Schur plan of a structure, timed; out[0..7] = nc, nl, no, n_pairs, n_sblk, n_items, n_multi,
