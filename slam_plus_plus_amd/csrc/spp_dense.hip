@@ -1186,6 +1186,18 @@ void dense_aux_park(int device, hipStream_t s)
 		(void)hipStreamDestroy(s);
 		return;
 	}
+	// No stream may be left alive at process exit (the runtime's own teardown of a leftover CU-masked stream crashed under
+	// rocprofv3): the first parked stream registers a handler, which runs before the destructors of everything loaded earlier
+	static bool registered = false;
+	if(!registered) {
+		registered = true;
+		atexit([]() {
+			std::lock_guard<std::mutex> lock2(aux_pool_mutex);
+			for(size_t i = 0; i < aux_pool.size(); ++ i)
+				(void)hipStreamDestroy(aux_pool[i].second);
+			aux_pool.clear();
+		});
+	}
 	aux_pool.push_back(std::make_pair(device, s));
 }
 
