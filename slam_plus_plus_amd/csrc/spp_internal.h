@@ -463,8 +463,13 @@ inline int plan_threads(int64_t work)
 		const char *e = getenv("SPP_PLAN_THREADS"); // host threads of the symbolic phase (default: up to 16)
 		env = e ? std::max(1, atoi(e)) : 0;
 	}
+	static int64_t min_work = -1;
+	if(min_work < 0) {
+		const char *e = getenv("SPP_PLAN_MIN_WORK"); // (tests: 1 cuts even the smallest problem among the threads)
+		min_work = e ? std::max<int64_t>(1, atoll(e)) : (int64_t(1) << 18);
+	}
 	int nt = env ? env : (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
-	if(work < (int64_t(1) << 18))
+	if(work < min_work)
 		nt = 1; // small problems: a thread costs more than it saves
 	return std::min(nt, 64);
 }

@@ -26,9 +26,11 @@ print(json.dumps(d))
 """
 
 
-def _plan(name, threads, rank=0, world=1, sparse=False):
+def _plan(name, threads, rank=0, world=1, sparse=False, min_work=None):
     import json
     env = dict(os.environ, SPP_PLAN_THREADS=str(threads))
+    if min_work is not None:
+        env["SPP_PLAN_MIN_WORK"] = str(min_work)
     r = subprocess.run([sys.executable, "-c", CHILD % ROOT, name, str(rank), str(world), "1" if sparse else "0"], env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
@@ -58,6 +60,18 @@ def test_plan_does_not_depend_on_the_thread_count():
     a = _plan("ba_medium", 1)
     b = _plan("ba_medium", 4)
     c = _plan("ba_medium", 7)
+    assert a == b == c, (a, b, c)
+
+
+@pytest.mark.parametrize("name,rank,world,sparse", [("ba_small", 0, 1, False), ("ba_interleaved", 0, 1, False),
+                                                   ("ba_medium", 1, 2, False), ("ba_banded", 1, 2, True)])
+def test_every_pass_cut_among_threads_gives_the_same_plan(name, rank, world, sparse):
+    """SPP_PLAN_MIN_WORK=1 cuts every pass (observation scan, camera lists, pair lists by row of S) among the threads
+    even on a small graph: more threads than some ranges have columns, the unsorted-observation fallback of the
+    interleaved numbering, a landmark shard, and the union pattern of a sharded sparse S"""
+    a = _plan(name, 1, rank, world, sparse)
+    b = _plan(name, 5, rank, world, sparse, min_work=1)
+    c = _plan(name, 16, rank, world, sparse, min_work=1)
     assert a == b == c, (a, b, c)
 
 
