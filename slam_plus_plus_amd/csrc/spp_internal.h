@@ -234,6 +234,8 @@ struct SchurPlan {
 	std::vector<uint8_t> is_lm;      // per block column: eliminated by the Schur complement (any shard)
 	// device arrays
 	DevBuf<int32_t> lm_ptr;        // [nl+1] first obs of landmark
+	DevBuf<int32_t> bs_ptr;        // [n_bs+1] landmark ranges of the fused back-substitution (at most 256 observations each); n_bs = 0: two launches
+	int64_t n_bs = 0;
 	DevBuf<int64_t> lm_coff;       // [nl] offset of C block in vals
 	DevBuf<int64_t> lm_rbase;      // [nl] scalar offset of the landmark in rhs
 	DevBuf<int32_t> obs_pose;      // [no] reduced pose index

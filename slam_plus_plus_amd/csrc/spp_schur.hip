@@ -820,6 +820,69 @@ void backsubst_lm_kernel(int64_t nl, const int32_t *__restrict__ lm_ptr, const i
 	}
 }
 
+// Both steps in one launch: a workgroup takes a group of consecutive landmarks with at most 256 observations between them
+// (bs_ptr, built with the plan), forms the products U_a^T dx one lane per observation into LDS, then one lane per landmark
+// adds them in observation order and applies -C^-1 -- the same operations in the same order as the two kernels above,
+// without the round trip of the products through memory (24 B per observation written and read back) and its launch.
+template <int DP, int DL>
+__global__ __launch_bounds__(256)
+void backsubst_fused_kernel(const int32_t *__restrict__ bs_ptr, const int32_t *__restrict__ lm_ptr, const int32_t *__restrict__ obs_pose,
+	const int64_t *__restrict__ obs_off, const int64_t *__restrict__ lm_rbase, const double *__restrict__ cinv,
+	const int64_t *__restrict__ lm_coff, const double *__restrict__ vals, const double *__restrict__ dx, double *__restrict__ rhs)
+{
+	__shared__ double tq[256 * DL];
+	const int32_t l0 = bs_ptr[blockIdx.x], l1 = bs_ptr[blockIdx.x + 1];
+	const int32_t a0 = lm_ptr[l0], na = lm_ptr[l1] - a0;
+	const int t = threadIdx.x;
+	if(t < na) {
+		const int64_t a = (int64_t)a0 + t;
+		double u[DP * DL];
+		load_U<DP, DL>(vals, obs_off[a], u);
+		double dv[DP];
+		const double *d = dx + (int64_t)obs_pose[a] * DP;
+#pragma unroll
+		for(int r = 0; r < DP; ++ r)
+			dv[r] = d[r];
+#pragma unroll
+		for(int q = 0; q < DL; ++ q) {
+			double sum = 0;
+#pragma unroll
+			for(int r = 0; r < DP; ++ r)
+				sum += dv[r] * u[r + DP * q];
+			tq[t * DL + q] = sum;
+		}
+	}
+	__syncthreads();
+	if(t >= l1 - l0)
+		return;
+	const int64_t l = (int64_t)l0 + t;
+	double tv[DL];
+	const int64_t rb = lm_rbase[l];
+#pragma unroll
+	for(int q = 0; q < DL; ++ q)
+		tv[q] = -rhs[rb + q]; // v_l = -v_l, LinearSolver_Schur.h:1867
+	for(int32_t a = lm_ptr[l] - a0, e = lm_ptr[l + 1] - a0; a < e; ++ a) {
+#pragma unroll
+		for(int q = 0; q < DL; ++ q)
+			tv[q] += tq[a * DL + q];
+	}
+	double Ci[DL * DL];
+	if(cinv) {
+#pragma unroll
+		for(int e = 0; e < DL * DL; ++ e)
+			Ci[e] = cinv[l * DL * DL + e];
+	} else
+		cinv_block<DL>(vals + lm_coff[l], Ci);
+#pragma unroll
+	for(int q = 0; q < DL; ++ q) {
+		double sum = 0;
+#pragma unroll
+		for(int u = 0; u < DL; ++ u)
+			sum += Ci[q + DL * u] * tv[u];
+		rhs[rb + q] = sum;
+	}
+}
+
 template <int DP>
 __global__ __launch_bounds__(256)
 void scatter_dx_kernel(int64_t nc, const int64_t *__restrict__ pose_rbase, const double *__restrict__ dx,
@@ -924,12 +987,23 @@ static int schur_finish_t(spp_ctx *ctx, const double *d_vals, double *S, double 
 	}
 	phase_begin(ctx, SPP_PHASE_BACKSUBST);
 	static_assert(DL <= DP, "the products U^T dx reuse the W l buffer (DP doubles per observation)");
-	if(sp.no)
-		hipLaunchKernelGGL((backsubst_obs_kernel<DP, DL>), dim3((unsigned)((sp.no + 255) / 256)), dim3(256), 0, s,
-			sp.no, sp.obs_pose.p, sp.obs_off.p, d_vals, xcol, sp.xw.p);
-	if(sp.nl)
-		hipLaunchKernelGGL((backsubst_lm_kernel<DL>), dim3((unsigned)((sp.nl + 255) / 256)), dim3(256), 0, s,
-			sp.nl, sp.lm_ptr.p, sp.lm_rbase.p, sp.xw.p, (sp.factored && DL <= 3) ? (const double*)nullptr : (const double*)sp.cinv.p, sp.lm_coff.p, d_vals, d_rhs);
+	static int bs_fused = -1;
+	if(bs_fused < 0) {
+		const char *e = getenv("SPP_BACKSUBST_FUSED"); // 0: the products U^T dx through memory, two launches (rounds 1-3)
+		bs_fused = e ? atoi(e) : 1;
+	}
+	const double *cinv_arg = (sp.factored && DL <= 3) ? (const double*)nullptr : (const double*)sp.cinv.p;
+	if(bs_fused && sp.n_bs > 0)
+		hipLaunchKernelGGL((backsubst_fused_kernel<DP, DL>), dim3((unsigned)sp.n_bs), dim3(256), 0, s,
+			sp.bs_ptr.p, sp.lm_ptr.p, sp.obs_pose.p, sp.obs_off.p, sp.lm_rbase.p, cinv_arg, sp.lm_coff.p, d_vals, xcol, d_rhs);
+	else {
+		if(sp.no)
+			hipLaunchKernelGGL((backsubst_obs_kernel<DP, DL>), dim3((unsigned)((sp.no + 255) / 256)), dim3(256), 0, s,
+				sp.no, sp.obs_pose.p, sp.obs_off.p, d_vals, xcol, sp.xw.p);
+		if(sp.nl)
+			hipLaunchKernelGGL((backsubst_lm_kernel<DL>), dim3((unsigned)((sp.nl + 255) / 256)), dim3(256), 0, s,
+				sp.nl, sp.lm_ptr.p, sp.lm_rbase.p, sp.xw.p, cinv_arg, sp.lm_coff.p, d_vals, d_rhs);
+	}
 	if(sp.nc)
 		hipLaunchKernelGGL((scatter_dx_kernel<DP>), dim3((unsigned)((sp.nc * DP + 255) / 256)), dim3(256), 0, s,
 			sp.nc, sp.pose_rbase.p, xcol, d_rhs);

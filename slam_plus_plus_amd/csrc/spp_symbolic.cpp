@@ -29,7 +29,7 @@ namespace spp {
 
 void SchurPlan::release_all()
 {
-	lm_ptr.release(); lm_coff.release(); lm_rbase.release(); obs_pose.release(); obs_lm.release();
+	lm_ptr.release(); bs_ptr.release(); n_bs = 0; lm_coff.release(); lm_rbase.release(); obs_pose.release(); obs_lm.release();
 	obs_off.release(); pose_rbase.release(); cam_ptr.release(); cam_obs.release(); items.release();
 	obs_wpos.release(); xcd_beg.release(); sblk_i1.release(); sblk_i2.release(); sblk_aoff.release();
 	sblk_voff.release(); s_st = Structure(); sparse_S = false; mis = false;
@@ -170,6 +170,7 @@ struct SchurPlanHost {
 	std::vector<int64_t> pose_block, lm_block;
 	std::vector<uint8_t> is_lm;
 	HVec<int32_t> lm_ptr, obs_pose, obs_lm, cam_obs, wpos; // (per observation / landmark: HVec = not zero-filled, huge pages)
+	std::vector<int32_t> bs_ptr; // landmark ranges of at most BS_OBS observations (fused back-substitution); empty: a landmark has more
 	std::vector<int32_t> cam_ptr, sblk_i1, sblk_i2, multi_blk, multi_ptr, xb;
 	RawBuf<int32_t> pair_a, pair_b; // (tens of millions of entries: not value-initialized, first touched by the threads that fill them)
 	HVec<int64_t> lm_coff, obs_off, lm_rbase;
@@ -376,6 +377,32 @@ static void schur_plan_host(const Structure &st, int shard_rank, int shard_world
 	});
 	for(int64_t l = (no ? obs_lm[no - 1] : -1) + 1; l <= nl; ++ l)
 		lm_ptr[l] = (int32_t)no;
+
+	// ---- back-substitution: consecutive landmarks in groups of at most 256 observations (one workgroup each: the products
+	// U^T dx of a group stay in LDS, spp_schur.hip backsubst_fused_kernel)
+	{
+		const int32_t BS_OBS = 256;
+		std::vector<int32_t> &bp = h.bs_ptr;
+		bp.clear();
+		bp.reserve((size_t)(no / 160 + 2));
+		bp.push_back(0);
+		int32_t first = 0;
+		bool ok = true;
+		for(int64_t l = 0; l < nl; ++ l) {
+			if(lm_ptr[l + 1] - lm_ptr[l] > BS_OBS) {
+				ok = false;
+				break;
+			}
+			if(lm_ptr[l + 1] - lm_ptr[first] > BS_OBS || l - first >= BS_OBS) { // (one lane per observation, then one per landmark)
+				bp.push_back((int32_t)l);
+				first = (int32_t)l;
+			}
+		}
+		if(ok && nl)
+			bp.push_back((int32_t)nl);
+		else
+			bp.clear();
+	}
 
 	// ---- per-pose observation lists (ascending landmark = ascending obs index): a counting sort by camera, ranges of
 	// observations on host threads (per-range, per-camera counts give every range its place in every camera's list)
@@ -810,6 +837,8 @@ void build_schur_plan(spp_ctx *ctx, bool sparse_S, bool mis)
 	// ---- upload
 	sp.xcd_beg.upload(h.xb, s);
 	sp.lm_ptr.upload(h.lm_ptr, s);
+	sp.n_bs = h.bs_ptr.empty() ? 0 : (int64_t)h.bs_ptr.size() - 1;
+	sp.bs_ptr.upload(h.bs_ptr, s);
 	sp.lm_coff.upload(h.lm_coff, s);
 	sp.lm_rbase.upload(h.lm_rbase, s);
 	sp.obs_pose.upload(h.obs_pose, s);
